@@ -1,0 +1,552 @@
+// csrc/dqn_api.hip -- the C ABI of libdqn_hip.so (include/dqn_hip.h): handle, device arena,
+// kernel sequencing, hipGraph capture of the fused update, RCCL gradient all-reduce.
+#include "../../include/dqn_hip.h"
+#include "dqn_launch.h"
+
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do { hipError_t e_ = (expr);                                                               \
+         if (e_ != hipSuccess) return fail(DQN_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(DQN_ERR_INVALID, __VA_ARGS__); } while (0)
+
+extern "C" const char *dqn_last_error(void) { return g_err.c_str(); }
+extern "C" int dqn_abi_version(void) { return DQN_ABI_VERSION; }
+
+extern "C" void dqn_default_config(dqn_config *c) {
+    // Test/lunar_lander.py:23-48 + LunarLander/dddqn.py:19-22 + optax defaults
+    memset(c, 0, sizeof(*c));
+    c->obs_dim = 9; c->hidden1 = 32; c->hidden2 = 64; c->num_actions = 4;
+    c->capacity = 100000; c->use_per = 0; c->max_batch = 64;
+    c->optimizer = DQN_OPT_ADAMW; c->lr = 2e-4f; c->b1 = 0.9f; c->b2 = 0.999f; c->eps = 1e-8f;
+    c->weight_decay = 1e-4f; c->gamma = 0.99f;
+    c->per_alpha = 0.6f; c->per_eps = 1e-6f; c->per_beta = 0.4f;
+    c->precision = DQN_PREC_F32; c->seed = 0; c->world_size = 1;
+}
+
+// ------------------------------------------------------------------------------ handle
+struct GraphSet { hipGraphExec_t fused = nullptr, bwd = nullptr, apply = nullptr; };
+
+// RCCL entry points, resolved lazily so the library loads without librccl
+struct NcclId { char b[128]; };   // ncclUniqueId (passed by value to ncclCommInitRank)
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+struct dqn_handle {
+    dqn_config cfg;
+    NetDims m;
+    int L = 0;                 // tree levels (N_tree = 2^L >= capacity)
+    long long Ntree = 0;
+    int Bp = 0;                // max_batch rounded up to 16
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    DqnState *st = nullptr;
+    float *params = nullptr, *target = nullptr, *mu = nullptr, *nu = nullptr, *grad = nullptr;
+    float *pack = nullptr, *pack_t = nullptr;
+    float *states = nullptr, *observations = nullptr, *rewards = nullptr;
+    int32_t *actions = nullptr; uint8_t *dones = nullptr;
+    float *tree = nullptr; unsigned long long *stamp = nullptr;
+    float *bs = nullptr, *bs2 = nullptr, *br = nullptr, *bw_raw = nullptr, *bisw = nullptr, *btd = nullptr,
+          *btd_abs = nullptr, *bdf = nullptr;
+    int32_t *ba = nullptr, *bidx = nullptr; uint8_t *bd = nullptr;
+    float *q = nullptr, *nq = nullptr, *nt = nullptr;
+    float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
+    float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
+    std::map<int, GraphSet> graphs;
+    void *comm = nullptr; int rank = 0, world = 1;
+    std::map<int, std::pair<void *, int64_t>> bufs;
+};
+
+static Rccl g_rccl;
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
+    REQUIRE(cfg && out, "dqn_create: null argument");
+    const int D = cfg->obs_dim, H1 = cfg->hidden1, H2 = cfg->hidden2, A = cfg->num_actions;
+    REQUIRE(D >= 1 && D <= 256, "obs_dim %d out of range [1,256]", D);
+    REQUIRE(H1 >= 16 && H1 <= 256 && H1 % 16 == 0, "hidden1 %d must be a multiple of 16 in [16,256]", H1);
+    REQUIRE(H2 >= 16 && H2 <= 256 && H2 % 16 == 0, "hidden2 %d must be a multiple of 16 in [16,256]", H2);
+    REQUIRE(A >= 1 && A <= 15, "num_actions %d out of range [1,15]", A);
+    REQUIRE(cfg->capacity >= 1 && cfg->capacity <= (1ll << 30), "capacity out of range");
+    REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= (1 << 22), "max_batch out of range");
+    REQUIRE(cfg->precision == DQN_PREC_F32, "precision %d not built (f32 only in this build)", cfg->precision);
+    REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
+    REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
+
+    dqn_handle *h = new (std::nothrow) dqn_handle();
+    if (!h) return fail(DQN_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->m = make_dims(D, H1, H2, A);
+    h->world = cfg->world_size;
+    h->Bp = (cfg->max_batch + 15) / 16 * 16;
+    if (cfg->use_per) {
+        int L = 0; while ((1ll << L) < cfg->capacity) ++L;
+        if (L < 1) L = 1;
+        h->L = L; h->Ntree = 1ll << L;
+    }
+    const long long N = cfg->capacity, P = h->m.P, Bp = h->Bp;
+    const int K1 = h->m.KQ1 * 16;
+
+    // carve one arena
+    struct Item { void **p; size_t bytes; int id; };
+    std::vector<Item> items;
+    auto add = [&](void *pp, size_t bytes, int id = -1) { items.push_back({(void **)pp, bytes, id}); };
+    add(&h->st, sizeof(DqnState));
+    add(&h->params, P * 4, DQN_BUF_PARAMS); add(&h->target, P * 4, DQN_BUF_TARGET);
+    add(&h->mu, P * 4, DQN_BUF_MU); add(&h->nu, P * 4, DQN_BUF_NU); add(&h->grad, P * 4, DQN_BUF_GRAD);
+    add(&h->pack, h->m.pack_floats * 4); add(&h->pack_t, h->m.pack_floats * 4);
+    add(&h->states, N * D * 4, DQN_BUF_STATES); add(&h->observations, N * D * 4, DQN_BUF_OBSERVATIONS);
+    add(&h->rewards, N * 4, DQN_BUF_REWARDS); add(&h->actions, N * 4, DQN_BUF_ACTIONS);
+    add(&h->dones, N, DQN_BUF_DONES);
+    if (cfg->use_per) { add(&h->tree, 2 * h->Ntree * 4, DQN_BUF_TREE); add(&h->stamp, h->Ntree * 8); }
+    add(&h->bs, Bp * D * 4); add(&h->bs2, Bp * D * 4); add(&h->br, Bp * 4); add(&h->bw_raw, Bp * 4);
+    add(&h->bisw, Bp * 4, DQN_BUF_BATCH_ISW); add(&h->btd, Bp * 4, DQN_BUF_BATCH_TD); add(&h->btd_abs, Bp * 4);
+    add(&h->bdf, Bp * 4); add(&h->ba, Bp * 4); add(&h->bidx, Bp * 4, DQN_BUF_BATCH_IDX); add(&h->bd, Bp);
+    add(&h->q, Bp * A * 4); add(&h->nq, Bp * A * 4); add(&h->nt, Bp * A * 4);
+    add(&h->px, Bp * K1 * 4); add(&h->ph1, Bp * H1 * 4); add(&h->ph2, Bp * H2 * 4);
+    add(&h->pdz1, Bp * H1 * 4); add(&h->pdz2, Bp * H2 * 4); add(&h->pdz3, Bp * 16 * 4);
+    add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
+    size_t total = 0;
+    for (auto &it : items) total += align_up(it.bytes, 256);
+    hipError_t e = hipMalloc(&h->arena, total);
+    if (e != hipSuccess) { delete h; return fail(DQN_ERR_NOMEM, "hipMalloc(%zu bytes): %s", total, hipGetErrorString(e)); }
+    h->arena_bytes = total;
+    e = hipMemset(h->arena, 0, total);                   // zero ring (replay_buffer.py:28-32), tree, moments
+    if (e != hipSuccess) { hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "hipMemset: %s", hipGetErrorString(e)); }
+    size_t off = 0;
+    for (auto &it : items) {
+        *it.p = (char *)h->arena + off;
+        if (it.id >= 0) h->bufs[it.id] = {*it.p, (int64_t)it.bytes};
+        off += align_up(it.bytes, 256);
+    }
+    DqnState s0{};
+    s0.b1pow = 1.0; s0.b2pow = 1.0; s0.pmax = 1.0f; s0.beta = cfg->per_beta; s0.lr = cfg->lr;
+    e = hipMemcpy(h->st, &s0, sizeof(s0), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "state init: %s", hipGetErrorString(e)); }
+    *out = h;
+    return DQN_OK;
+}
+
+static void destroy_graphs(dqn_handle *h) {
+    for (auto &kv : h->graphs) {
+        if (kv.second.fused) hipGraphExecDestroy(kv.second.fused);
+        if (kv.second.bwd) hipGraphExecDestroy(kv.second.bwd);
+        if (kv.second.apply) hipGraphExecDestroy(kv.second.apply);
+    }
+    h->graphs.clear();
+}
+
+extern "C" int dqn_destroy(dqn_handle *h) {
+    if (!h) return DQN_OK;
+    hipDeviceSynchronize();
+    destroy_graphs(h);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->arena) hipFree(h->arena);
+    delete h;
+    return DQN_OK;
+}
+
+extern "C" int dqn_param_count(const dqn_handle *h, int64_t *n) {
+    REQUIRE(h && n, "null argument");
+    *n = h->m.P;
+    return DQN_OK;
+}
+
+static float *param_buf(dqn_handle *h, int which) {
+    switch (which) {
+    case DQN_BUF_PARAMS: return h->params; case DQN_BUF_TARGET: return h->target;
+    case DQN_BUF_MU: return h->mu; case DQN_BUF_NU: return h->nu; case DQN_BUF_GRAD: return h->grad;
+    default: return nullptr;
+    }
+}
+
+extern "C" int dqn_set_params(dqn_handle *h, int which, const float *src, int src_is_host, void *stream) {
+    REQUIRE(h && src, "null argument");
+    float *dst = param_buf(h, which);
+    REQUIRE(dst, "dqn_set_params: bad selector %d", which);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(dst, src, h->m.P * 4, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    if (which == DQN_BUF_PARAMS) launch_pack(s, h->m, h->params, h->pack);
+    if (which == DQN_BUF_TARGET) launch_pack(s, h->m, h->target, h->pack_t);
+    HIP_TRY(hipGetLastError());
+    if (src_is_host) HIP_TRY(hipStreamSynchronize(s));      // the host buffer may be pageable / reused
+    return DQN_OK;
+}
+
+extern "C" int dqn_get_params(dqn_handle *h, int which, float *dst, int dst_is_host, void *stream) {
+    REQUIRE(h && dst, "null argument");
+    float *src = param_buf(h, which);
+    REQUIRE(src, "dqn_get_params: bad selector %d", which);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(dst, src, h->m.P * 4, dst_is_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    if (dst_is_host) HIP_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+extern "C" int dqn_set_opt_count(dqn_handle *h, int32_t count, void *stream) {
+    REQUIRE(h && count >= 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const double b1pow = std::pow((double)h->cfg.b1, (double)count), b2pow = std::pow((double)h->cfg.b2, (double)count);
+    HIP_TRY(hipMemcpyAsync(&h->st->b1pow, &b1pow, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(&h->st->b2pow, &b2pow, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(&h->st->adam_count, &count, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+extern "C" int dqn_get_opt_count_host(dqn_handle *h, int32_t *count) {
+    REQUIRE(h && count, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(count, &h->st->adam_count, 4, hipMemcpyDeviceToHost));
+    return DQN_OK;
+}
+
+extern "C" int dqn_buffer(dqn_handle *h, int which, void **ptr, int64_t *nbytes) {
+    REQUIRE(h && ptr && nbytes, "null argument");
+    auto it = h->bufs.find(which);
+    REQUIRE(it != h->bufs.end(), "dqn_buffer: selector %d not available on this handle", which);
+    *ptr = it->second.first; *nbytes = it->second.second;
+    return DQN_OK;
+}
+
+extern "C" int dqn_set_schedule(dqn_handle *h, float per_beta, float lr, void *stream) {
+    REQUIRE(h, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    h->cfg.per_beta = per_beta; h->cfg.lr = lr;
+    HIP_TRY(hipMemcpyAsync(&h->st->beta, &h->cfg.per_beta, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(&h->st->lr, &h->cfg.lr, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+// ------------------------------------------------------------------------------ replay
+extern "C" int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, const float *r,
+                              const float *s2, const uint8_t *d, int32_t n, void *stream) {
+    REQUIRE(h && s && a && r && s2 && d, "null argument");
+    REQUIRE(n >= 1 && n <= h->cfg.capacity, "dqn_replay_add: n=%d must be in [1, capacity]", n);
+    hipStream_t st = (hipStream_t)stream;
+    launch_replay_add(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
+                      h->cfg.capacity, h->cfg.obs_dim, s, a, r, s2, d, n);
+    if (h->cfg.use_per)
+        launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, nullptr, nullptr, n, 2,
+                         h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter) {
+    REQUIRE(h, "null argument");
+    DqnState s;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&s, h->st, sizeof(s), hipMemcpyDeviceToHost));
+    if (size) *size = s.size;
+    if (counter) *counter = (int64_t)s.ring_counter;
+    return DQN_OK;
+}
+
+extern "C" int dqn_replay_sample_uniform(dqn_handle *h, int32_t B, uint64_t seed, uint64_t ctr,
+                                         const int32_t *idx_in, float *s, int32_t *a, float *r,
+                                         float *s2, uint8_t *d, int32_t *idx_out, void *stream) {
+    REQUIRE(h && s && a && r && s2 && d, "null argument");
+    REQUIRE(B >= 1, "B must be >= 1");
+    launch_sample_uniform((hipStream_t)stream, h->st, h->states, h->actions, h->rewards, h->observations,
+                          h->dones, h->cfg.obs_dim, B, seed, ctr, 0, idx_in, s, a, r, s2, d, idx_out);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_per_sample(dqn_handle *h, int32_t B, float beta, uint64_t seed, uint64_t ctr,
+                              float *s, int32_t *a, float *r, float *s2, uint8_t *d,
+                              int32_t *idx, float *isw, void *stream) {
+    REQUIRE(h && s && a && r && s2 && d && idx && isw, "null argument");
+    if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "dqn_per_sample on a handle created with use_per=0");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
+                      h->dones, h->cfg.obs_dim, B, beta, seed, ctr, 0, s, a, r, s2, d, idx, h->bw_raw);
+    launch_isw_normalize(st, h->bw_raw, B, isw, h->st);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+static int per_write(dqn_handle *h, const int32_t *idx, const float *val, int32_t B, int mode, void *stream) {
+    REQUIRE(h && idx && val, "null argument");
+    if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
+    REQUIRE(B >= 1, "B must be >= 1");
+    launch_per_write((hipStream_t)stream, h->st, h->tree, h->stamp, h->Ntree, h->L, idx, val, B, mode,
+                     h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+extern "C" int dqn_per_update(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream) {
+    return per_write(h, idx, td_abs, B, 1, stream);
+}
+extern "C" int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream) {
+    return per_write(h, idx, prio, B, 0, stream);
+}
+
+// ------------------------------------------------------------------------------ network
+static FwdPass make_pass(dqn_handle *h, int which_net, const float *x, float *q, float *feat, bool stash) {
+    FwdPass p{};
+    p.x = x;
+    p.params = which_net == DQN_NET_TARGET ? h->target : h->params;
+    p.pack = which_net == DQN_NET_TARGET ? h->pack_t : h->pack;
+    p.q = q; p.feat = feat;
+    if (stash) { p.px = h->px; p.ph1 = h->ph1; p.ph2 = h->ph2; }
+    return p;
+}
+
+extern "C" int dqn_qnet_forward(dqn_handle *h, int which_net, const float *x, int32_t B,
+                                float *q, float *feat, void *stream) {
+    REQUIRE(h && x && q, "null argument");
+    REQUIRE(which_net == DQN_NET_ONLINE || which_net == DQN_NET_TARGET, "bad net selector");
+    REQUIRE(B >= 1, "B must be >= 1");
+    FwdPass p = make_pass(h, which_net, x, q, feat, false);
+    launch_qnet_fwd((hipStream_t)stream, h->m, &p, 1, B);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_td_targets(dqn_handle *h, const float *q, const float *next_q, const float *next_q_tm,
+                              const int32_t *a, const float *r, const float *d, const float *isw,
+                              float gamma, int32_t B, float *targets, float *td, float *dq, float *loss,
+                              void *stream) {
+    REQUIRE(h && q && next_q && next_q_tm && a && r && d, "null argument");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    launch_td((hipStream_t)stream, q, next_q, next_q_tm, a, r, d, isw, gamma, B, h->cfg.num_actions,
+              targets, td, dq, loss, h->scratch);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_q_targets(dqn_handle *h, const float *s, const int32_t *a, const float *r,
+                             const float *s2, const float *d, int32_t B, float *targets, void *stream) {
+    REQUIRE(h && s && a && r && s2 && d && targets, "null argument");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false),      // :52
+                     make_pass(h, DQN_NET_ONLINE, s2, h->nq, nullptr, false),    // :53
+                     make_pass(h, DQN_NET_TARGET, s2, h->nt, nullptr, false) };  // :54
+    launch_qnet_fwd(st, h->m, p, 3, B);
+    launch_td(st, h->q, h->nq, h->nt, a, r, d, nullptr, h->cfg.gamma, B, h->cfg.num_actions, targets,
+              nullptr, nullptr, nullptr, h->scratch);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_loss(dqn_handle *h, const float *s, const float *targets, const float *isw,
+                        int32_t B, float *loss, void *stream) {
+    REQUIRE(h && s && targets && loss, "null argument");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false);
+    launch_qnet_fwd(st, h->m, &p, 1, B);
+    launch_loss(st, h->q, targets, isw, B, h->cfg.num_actions, loss);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, const float *isw,
+                         int32_t B, float *loss, void *stream) {
+    REQUIRE(h && s && targets, "null argument");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, true);
+    launch_qnet_fwd(st, h->m, &p, 1, B);
+    BwdArgs g{};
+    g.q = h->q; g.targets = targets; g.isw = isw; g.gamma = h->cfg.gamma;
+    g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
+    g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3; g.loss_part = h->loss_part;
+    launch_bwd_rows(st, h->m, g, B, h->st);
+    launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
+              loss ? loss : h->loss_dev, h->st, 0);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+static void enqueue_adam(dqn_handle *h, hipStream_t st) {
+    launch_adam(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack,
+                h->cfg.optimizer == DQN_OPT_ADAMW, h->cfg.b1, h->cfg.b2, h->cfg.eps, h->cfg.weight_decay,
+                1.0f / (float)h->world);
+}
+
+extern "C" int dqn_optimizer_step(dqn_handle *h, void *stream) {
+    REQUIRE(h, "null argument");
+    enqueue_adam(h, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_train_step(dqn_handle *h, const float *s, const float *targets, int32_t B, void *stream) {
+    int rc = dqn_grads(h, s, targets, nullptr, B, nullptr, stream);
+    if (rc != DQN_OK) return rc;
+    return dqn_optimizer_step(h, stream);
+}
+
+// ------------------------------------------------------------------------ fused update
+static void enqueue_backward(dqn_handle *h, int B, hipStream_t st) {
+    // q_agent.py:147-153 sample_batch
+    if (h->cfg.use_per)
+        launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
+                          h->dones, h->cfg.obs_dim, B, 0.f, h->cfg.seed, 0, 1, h->bs, h->ba, h->br, h->bs2, h->bd,
+                          h->bidx, h->bw_raw);
+    else
+        launch_sample_uniform(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
+                              h->cfg.obs_dim, B, h->cfg.seed, 0, 1, nullptr, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx);
+    // q_agent.py:159-165 compute_q_targets: three forwards
+    FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, true),
+                     make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),
+                     make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false) };
+    launch_qnet_fwd(st, h->m, p, 3, B);
+    // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
+    BwdArgs g{};
+    g.q = h->q; g.nq = h->nq; g.nt = h->nt; g.a = h->ba; g.r = h->br; g.d_u8 = h->bd;
+    g.w_raw = h->cfg.use_per ? h->bw_raw : nullptr; g.gamma = h->cfg.gamma;
+    g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
+    g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
+    g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
+    launch_bwd_rows(st, h->m, g, B, h->st);
+    launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
+              h->loss_dev, h->st, 1);
+}
+
+static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
+    enqueue_adam(h, st);                                           // q_learning_functions.py:24-25
+    if (h->cfg.use_per)
+        launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
+                         h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+}
+
+// capture `body` into an executable graph on the caller's stream (non-null streams only)
+template <class F>
+static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F body) {
+    if (!st) { body(); HIP_TRY(hipGetLastError()); return DQN_OK; }   // legacy default stream: eager
+    if (!*slot) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        body();
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (e != hipSuccess) return fail(DQN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(slot, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) { *slot = nullptr; return fail(DQN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(hipGraphLaunch(*slot, st));
+    (void)h;
+    return DQN_OK;
+}
+
+static int check_B(dqn_handle *h, int32_t B) {
+    REQUIRE(h, "null argument");
+    REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
+    return DQN_OK;
+}
+
+extern "C" int dqn_update_fused(dqn_handle *h, int32_t B, void *stream) {
+    int rc = check_B(h, B); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return run_captured(h, &h->graphs[B].fused, st, [&] { enqueue_backward(h, B, st); enqueue_apply(h, B, st); });
+}
+extern "C" int dqn_update_backward(dqn_handle *h, int32_t B, void *stream) {
+    int rc = check_B(h, B); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return run_captured(h, &h->graphs[B].bwd, st, [&] { enqueue_backward(h, B, st); });
+}
+extern "C" int dqn_update_apply(dqn_handle *h, int32_t B, void *stream) {
+    int rc = check_B(h, B); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    return run_captured(h, &h->graphs[B].apply, st, [&] { enqueue_apply(h, B, st); });
+}
+
+extern "C" int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, uint64_t seed,
+                       uint64_t ctr, int32_t *actions, void *stream) {
+    REQUIRE(h && s && actions, "null argument");
+    REQUIRE(n >= 1 && n <= h->cfg.max_batch, "n=%d exceeds max_batch=%d", n, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false);
+    launch_qnet_fwd(st, h->m, &p, 1, n);
+    launch_policy(st, h->q, n, h->cfg.num_actions, epsilon, seed, ctr, actions);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {
+    REQUIRE(h, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->target, h->params, h->m.P * 4, hipMemcpyDeviceToDevice, st));   // q_agent.py:144
+    HIP_TRY(hipMemcpyAsync(h->pack_t, h->pack, h->m.pack_floats * 4, hipMemcpyDeviceToDevice, st));
+    return DQN_OK;
+}
+
+// -------------------------------------------------------------------------------- RCCL
+static int load_rccl() {
+    if (g_rccl.lib) return DQN_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(DQN_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(DQN_ERR_COMM, "librccl.so lacks a required symbol");
+    g_rccl.lib = lib;
+    return DQN_OK;
+}
+
+extern "C" int dqn_comm_unique_id(void *unique_id_128) {
+    REQUIRE(unique_id_128, "null argument");
+    int rc = load_rccl(); if (rc) return rc;
+    const int e = g_rccl.GetUniqueId(unique_id_128);
+    if (e) return fail(DQN_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}
+
+extern "C" int dqn_comm_init(dqn_handle *h, const void *unique_id_128, int32_t rank, int32_t world) {
+    REQUIRE(h && unique_id_128, "null argument");
+    REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world");
+    int rc = load_rccl(); if (rc) return rc;
+    NcclId id;
+    memcpy(&id, unique_id_128, 128);
+    const int e = g_rccl.CommInitRank(&h->comm, world, id, rank);
+    if (e) return fail(DQN_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    h->rank = rank; h->world = world; h->cfg.world_size = world;
+    destroy_graphs(h);                                        // grad scale is baked into captured launches
+    return DQN_OK;
+}
+
+extern "C" int dqn_allreduce_grads(dqn_handle *h, void *stream) {
+    REQUIRE(h, "null argument");
+    if (!h->comm) return fail(DQN_ERR_STATE, "dqn_allreduce_grads before dqn_comm_init");
+    // one in-place sum all-reduce of the flat f32 gradient (P elements); /world is in the optimizer
+    const int e = g_rccl.AllReduce(h->grad, h->grad, (size_t)h->m.P, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm,
+                                   (hipStream_t)stream);
+    if (e) return fail(DQN_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}

@@ -1,0 +1,87 @@
+// csrc/dqn_device.h -- shared device-side definitions (gfx950 only).
+// Compiled with -ffp-contract=off: every f32 op written here is one IEEE rounding, so the
+// integer/indexing paths (Philox, sum-tree, deterministic pow, Adam) are bit-reproducible
+// against the CPU restatement. FMA is used only where written explicitly (fmaf / MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Mutable scalars that must live on the device so that a hipGraph replay sees them change.
+struct DqnState {
+    unsigned long long ring_counter;   // ReplayBuffer._counter      (replay_buffer.py:33)
+    long long          size;           // ReplayBuffer._num_samples  (replay_buffer.py:34)
+    unsigned long long sample_ctr;     // Philox counter of the fused path (one per update)
+    unsigned long long epoch;          // write-back epoch for duplicate resolution
+    double             b1pow, b2pow;   // running b1^t, b2^t
+    int                adam_count;     // ScaleByAdamState.count
+    float              pmax;           // running max priority
+    float              beta;           // IS exponent for the fused path
+    float              lr;
+    float              loss;           // last loss
+    float              wmax;           // last batch's max raw IS weight
+    unsigned int       arrive;         // last-block tickets
+    unsigned int       pad;
+};
+
+enum { DQN_STREAM_PER = 0, DQN_STREAM_UNIFORM = 1, DQN_STREAM_POLICY = 2, DQN_STREAM_ENV = 3 };
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ u32x4 philox_draw(unsigned long long seed, unsigned long long ctr,
+                                             uint32_t k, uint32_t stream) {
+    return philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), k, stream,
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 0x1.0p-24f; }
+
+// ------------------------------------------------- deterministic f32 pow (no FMA)
+__device__ __forceinline__ float log2_det(float x) {
+    const uint32_t u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xFF) - 127;
+    float m = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = __fdiv_rn(m - 1.0f, m + 1.0f);
+    const float z = s * s;
+    float p = 0.111111112f;
+    p = p * z; p = p + 0.142857149f;
+    p = p * z; p = p + 0.2f;
+    p = p * z; p = p + 0.333333343f;
+    p = p * z; p = p + 1.0f;
+    const float ln_m = (2.0f * s) * p;
+    const float r = ln_m * 1.44269502f;
+    return (float)e + r;
+}
+
+__device__ __forceinline__ float exp2_det(float y) {
+    const float fi = floorf(y + 0.5f);
+    int i = (int)fi;
+    const float f = y - fi;
+    const float t = f * 0.693147182f;
+    float p = 1.98412701e-4f;
+    p = p * t; p = p + 1.38888892e-3f;
+    p = p * t; p = p + 8.33333377e-3f;
+    p = p * t; p = p + 4.16666679e-2f;
+    p = p * t; p = p + 0.166666672f;
+    p = p * t; p = p + 0.5f;
+    p = p * t; p = p + 1.0f;
+    p = p * t; p = p + 1.0f;
+    i = i < -126 ? -126 : (i > 127 ? 127 : i);
+    return p * __uint_as_float((uint32_t)(i + 127) << 23);
+}
+
+__device__ __forceinline__ float pow_det(float x, float a) { return exp2_det(a * log2_det(x)); }

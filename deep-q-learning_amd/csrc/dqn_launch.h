@@ -1,0 +1,79 @@
+// csrc/dqn_launch.h -- host-side launcher prototypes shared by dqn_api.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dqn_device.h"
+
+// ----- network geometry -----------------------------------------------------------------
+// Flat parameter layout (haiku leaf order, w is [in,out] row-major; LunarLander/dddqn.py:19-22):
+//   w1[D*H1] b1[H1] w2[H1*H2] b2[H2] wv[H2] bv[1] wa[H2*A] ba[A]
+struct NetDims {
+    int D, H1, H2, A;
+    int KQ1;            // ceil(D/16): 16-wide k-blocks of layer 1
+    long long o_w1, o_b1, o_w2, o_b2, o_wv, o_bv, o_wa, o_ba, P;
+    // fragment-packed shadows of the weights, as offsets (floats) into one pack buffer:
+    long long p_w1, p_w2, p_wh, p_w2t, p_wht, pack_floats;
+};
+NetDims make_dims(int D, int H1, int H2, int A);
+
+// Per-call description of one forward pass handled by k_qnet_fwd
+struct FwdPass {
+    const float *x;        // [B, D] row-major input rows
+    const float *params;   // flat params (biases are read from here)
+    const float *pack;     // fragment-packed weights of the same net
+    float *q;              // [B, A] out (may be NULL)
+    float *feat;           // [B, H2] row-major out (may be NULL)
+    float *px, *ph1, *ph2; // batch-major packed stashes for backward (may be NULL)
+};
+
+struct BwdArgs {
+    // inputs
+    const float *q, *nq, *nt;          // [B,A] (fused mode) ; q is also "pred"
+    const float *targets;              // [B,A] (parity mode) or NULL
+    const int32_t *a; const float *r; const uint8_t *d_u8; const float *d_f32;
+    const float *w_raw;                // raw IS weights (fused: normalised in-kernel) or NULL
+    const float *isw;                  // already-normalised weights (parity mode) or NULL
+    float gamma;
+    const float *ph1, *ph2;            // packed post-ReLU activations of the s-pass
+    const float *pack;                 // online net packs (p_w2t, p_wht used)
+    // outputs
+    float *pdz1, *pdz2, *pdz3;         // packed row-gradients for k_dw
+    float *td, *td_abs, *dq, *targets_out, *isw_out;   // optional [B] / [B,A]
+    float *loss_part;                  // [ceil(B/16)]
+};
+
+void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B);
+void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
+               const float *r, const float *d, const float *isw, float gamma, int B, int A,
+               float *targets, float *td, float *dq, float *loss, float *scratch);
+void launch_loss(hipStream_t s, const float *pred, const float *targets, const float *isw, int B, int A,
+                 float *loss);
+void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
+void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
+               const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
+               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr);
+void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
+                 float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
+void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
+                   unsigned long long ctr, int32_t *actions);
+void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
+
+// ----- replay / PER ---------------------------------------------------------------------
+void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
+                       float *observations, uint8_t *dones, long long N, int D, const float *s,
+                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n);
+void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,
+                           const float *rewards, const float *observations, const uint8_t *dones, int D,
+                           int B, unsigned long long seed, unsigned long long ctr, int from_state,
+                           const int32_t *idx_in, float *s, int32_t *a, float *r, float *s2, uint8_t *d,
+                           int32_t *idx_out);
+void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, long long N, int L,
+                       const float *states, const int32_t *actions, const float *rewards,
+                       const float *observations, const uint8_t *dones, int D, int B, float beta,
+                       unsigned long long seed, unsigned long long ctr, int from_state,
+                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw);
+void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st);
+void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
+                      int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,
+                      long long ring_capacity);

@@ -1,0 +1,247 @@
+// csrc/dqn_replay.hip -- replay ring and proportional-PER sum-tree kernels (gfx950).
+//
+// Integer / indexing work, HBM- (in practice Infinity-Cache-) bound. Bit-exact against the
+// CPU restatement: Philox draws, the f32 tree descent (compares and subtractions only), the
+// deterministic pow, and parents recomputed as left + right (never delta-added, no atomics
+// on tree values).
+//
+// Reference: General/Base/replay_buffer.py:20-85 (ring + uniform gather). PER is not in the
+// reference; SURVEY.md 8(c2) is its specification.
+#include "dqn_device.h"
+#include "dqn_launch.h"
+
+// ------------------------------------------------------------------ ring insert
+// ReplayBuffer.add (replay_buffer.py:58-65) for n rows at consecutive slots. Every block
+// reads the same ring_counter; the last block to finish commits counter and size.
+__global__ void __launch_bounds__(256)
+k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, float *observations,
+             uint8_t *dones, long long N, int D, const float *__restrict__ s,
+             const int32_t *__restrict__ a, const float *__restrict__ r,
+             const float *__restrict__ s2, const uint8_t *__restrict__ d, int n) {
+    const unsigned long long c0 = st->ring_counter;
+    const int total = n * D;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int j = t / D, e = t - j * D;
+        const long long k = (long long)((c0 + (unsigned long long)j) % (unsigned long long)N);
+        states[k * D + e] = s[t];                                       // :59
+        observations[k * D + e] = s2[t];                                // :62
+        if (e == 0) {
+            actions[k] = a[j];                                          // :60
+            rewards[k] = r[j];                                          // :61
+            dones[k] = d[j] ? 1 : 0;                                    // :63
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = atomicAdd(&st->arrive, 1u);
+        if (ticket == gridDim.x - 1) {
+            const unsigned long long c1 = c0 + (unsigned long long)n;
+            st->ring_counter = c1;                                                     // :64
+            st->size = (long long)(c1 < (unsigned long long)N ? c1 : (unsigned long long)N);  // :65
+            st->arrive = 0;
+            __threadfence();
+        }
+    }
+}
+
+// ------------------------------------------------------------- uniform sampling
+// sample_batch (replay_buffer.py:68-85): indices (given, or Philox stream 1) + 5 gathers.
+// One thread per sampled row; a row's D floats are contiguous.
+__device__ __forceinline__ void gather_row(const float *__restrict__ states, const int32_t *__restrict__ actions,
+                                           const float *__restrict__ rewards, const float *__restrict__ observations,
+                                           const uint8_t *__restrict__ dones, int D, long long i, int k,
+                                           float *s, int32_t *a, float *r, float *s2, uint8_t *d) {
+    const float *ps = states + i * D, *po = observations + i * D;
+    float *qs = s + (long long)k * D, *qo = s2 + (long long)k * D;
+    if ((D & 3) == 0) {
+        for (int e = 0; e < D; e += 4) {
+            *reinterpret_cast<float4 *>(qs + e) = *reinterpret_cast<const float4 *>(ps + e);
+            *reinterpret_cast<float4 *>(qo + e) = *reinterpret_cast<const float4 *>(po + e);
+        }
+    } else {
+        for (int e = 0; e < D; ++e) { qs[e] = ps[e]; qo[e] = po[e]; }
+    }
+    a[k] = actions[i];
+    r[k] = rewards[i];
+    d[k] = dones[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_uniform(const DqnState *st, const float *states, const int32_t *actions, const float *rewards,
+                 const float *observations, const uint8_t *dones, int D, int B,
+                 unsigned long long seed, unsigned long long ctr_arg, int from_state, const int32_t *idx_in,
+                 float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx_out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const unsigned long long ctr = from_state ? st->sample_ctr : ctr_arg;
+    long long i;
+    if (idx_in) {
+        i = idx_in[k];
+    } else {
+        const u32x4 o = philox_draw(seed, ctr, (uint32_t)k, DQN_STREAM_UNIFORM);
+        i = (long long)(((unsigned long long)o.x * (unsigned long long)st->size) >> 32);  // :77
+    }
+    if (idx_out) idx_out[k] = (int32_t)i;
+    gather_row(states, actions, rewards, observations, dones, D, i, k, s, a, r, s2, d);   // :78-84
+}
+
+// ------------------------------------------------------------------ PER sampling
+// Stratified proportional sampling: u_k = (k + U_k) * total / B, binary descent
+//   k=1; while k<N: l=tree[2k]; if u<l: k=2k else: u-=l; k=2k+1
+// clamp to < size, raw IS weight (size*p/total)^-beta via pow_det. One thread per sample.
+// ctr_from_state: take the Philox counter / beta from the device state (graph replay).
+__global__ void __launch_bounds__(256)
+k_per_sample(const DqnState *st, const float *__restrict__ tree, long long N, int L,
+             const float *states, const int32_t *actions, const float *rewards,
+             const float *observations, const uint8_t *dones, int D, int B, float beta_arg,
+             unsigned long long seed, unsigned long long ctr_arg, int from_state,
+             float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= B) return;
+    const unsigned long long ctr = from_state ? st->sample_ctr : ctr_arg;
+    const float beta = from_state ? st->beta : beta_arg;
+    const long long size = st->size;
+    const float total = tree[1];
+    const float seg = __fdiv_rn(total, (float)B);
+    const u32x4 o = philox_draw(seed, ctr, (uint32_t)k, DQN_STREAM_PER);
+    float u = ((float)k + u01(o.x)) * seg;
+    long long node = 1;
+    for (int lvl = 0; lvl < L; ++lvl) {
+        const float l = tree[2 * node];
+        if (u < l) { node = 2 * node; }
+        else { u = u - l; node = 2 * node + 1; }
+    }
+    long long leaf = node - N;
+    if (leaf >= size) leaf = size - 1;
+    idx[k] = (int32_t)leaf;
+    const float p = tree[N + leaf];
+    w_raw[k] = pow_det(__fdiv_rn((float)size * p, total), -beta);
+    gather_row(states, actions, rewards, observations, dones, D, leaf, k, s, a, r, s2, d);
+}
+
+// isw[k] = w_raw[k] / max_j w_raw[j]; every block recomputes the (order-independent) max.
+__global__ void __launch_bounds__(256)
+k_isw_normalize(const float *__restrict__ w_raw, int B, float *isw, DqnState *st) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int j = threadIdx.x; j < B; j += blockDim.x) m = fmaxf(m, w_raw[j]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
+        __syncthreads();
+    }
+    const float wmax = red[0];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < B) isw[k] = __fdiv_rn(w_raw[k], wmax);
+    if (k == 0) st->wmax = wmax;
+}
+
+// ------------------------------------------------------------- priority write-back
+// One workgroup (level-synchronous; all cross-level dependencies are inside it).
+//   mode 0: prio given            (dqn_per_set)
+//   mode 1: prio = (|td|+eps)^alpha (dqn_per_update)
+//   mode 2: leaves = last n ring slots, prio = pmax (ring insert with PER)
+// Duplicates: highest batch position wins, resolved with a 64-bit (epoch, position) stamp
+// per leaf. Parents are recomputed bottom-up as left + right; threads sharing a parent
+// store the same value.
+__global__ void __launch_bounds__(1024)
+k_per_write(DqnState *st, float *tree, unsigned long long *stamp, long long N, int L,
+            const int32_t *__restrict__ idx, const float *__restrict__ val, int B, int mode,
+            float alpha, float eps, long long ring_capacity) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const unsigned long long epoch = st->epoch + 1ull;
+    const float pmax_old = st->pmax;
+    unsigned long long c_base = 0;
+    if (mode == 2) c_base = st->ring_counter - (unsigned long long)B;   // slots just written
+    float lmax = 0.0f;
+
+    if (mode != 2) {
+        for (int i = tid; i < B; i += nt)
+            atomicMax(&stamp[idx[i]], (epoch << 32) | (unsigned long long)(unsigned)i);
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int i = tid; i < B; i += nt) {
+        long long leaf;
+        float p;
+        bool mine = true;
+        if (mode == 2) {
+            leaf = (long long)((c_base + (unsigned long long)i) % (unsigned long long)ring_capacity);
+            p = pmax_old;
+        } else {
+            leaf = idx[i];
+            p = (mode == 0) ? val[i] : pow_det(val[i] + eps, alpha);
+            mine = stamp[leaf] == ((epoch << 32) | (unsigned long long)(unsigned)i);
+            lmax = fmaxf(lmax, p);
+        }
+        if (mine) tree[N + leaf] = p;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int lvl = 1; lvl <= L; ++lvl) {
+        for (int i = tid; i < B; i += nt) {
+            const long long leaf = (mode == 2)
+                ? (long long)((c_base + (unsigned long long)i) % (unsigned long long)ring_capacity)
+                : (long long)idx[i];
+            const long long node = (N + leaf) >> lvl;
+            tree[node] = tree[2 * node] + tree[2 * node + 1];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (mode != 2) {
+        red[tid] = lmax;
+        __syncthreads();
+        for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+            if (tid < sft) red[tid] = fmaxf(red[tid], red[tid + sft]);
+            __syncthreads();
+        }
+        if (tid == 0) { st->pmax = fmaxf(pmax_old, red[0]); st->epoch = epoch; }
+    }
+}
+
+// --------------------------------------------------------------------- launchers
+void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
+                       float *observations, uint8_t *dones, long long N, int D, const float *s,
+                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n) {
+    const int total = n * D;
+    int blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_replay_add, dim3(blocks), dim3(256), 0, st_, st, states, actions, rewards,
+                       observations, dones, N, D, s, a, r, s2, d, n);
+}
+
+void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,
+                           const float *rewards, const float *observations, const uint8_t *dones, int D,
+                           int B, unsigned long long seed, unsigned long long ctr, int from_state,
+                           const int32_t *idx_in, float *s, int32_t *a, float *r, float *s2, uint8_t *d,
+                           int32_t *idx_out) {
+    hipLaunchKernelGGL(k_sample_uniform, dim3((B + 255) / 256), dim3(256), 0, st_, st, states, actions,
+                       rewards, observations, dones, D, B, seed, ctr, from_state, idx_in, s, a, r, s2, d, idx_out);
+}
+
+void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, long long N, int L,
+                       const float *states, const int32_t *actions, const float *rewards,
+                       const float *observations, const uint8_t *dones, int D, int B, float beta,
+                       unsigned long long seed, unsigned long long ctr, int from_state,
+                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw) {
+    hipLaunchKernelGGL(k_per_sample, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, states, actions,
+                       rewards, observations, dones, D, B, beta, seed, ctr, from_state, s, a, r, s2, d, idx, w_raw);
+}
+
+void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st) {
+    hipLaunchKernelGGL(k_isw_normalize, dim3((B + 255) / 256), dim3(256), 0, st_, w_raw, B, isw, st);
+}
+
+void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
+                      int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,
+                      long long ring_capacity) {
+    int threads = 64;
+    while (threads < B && threads < 1024) threads <<= 1;
+    hipLaunchKernelGGL(k_per_write, dim3(1), dim3(threads), 0, st_, st, tree, stamp, N, L, idx, val, B, mode,
+                       alpha, eps, ring_capacity);
+}

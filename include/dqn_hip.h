@@ -1,0 +1,167 @@
+/* include/dqn_hip.h -- C ABI of libdqn_hip.so: the MI355X (gfx950) DDDQN inner loop.
+ *
+ * The reference (hal9000universe/deep-q-learning) has no FFI/plugin boundary: its seam
+ * is a set of Python function factories returning jitted closures, wired in
+ * General/QLearning/q_agent.py:110-113 and called only from Agent._step (:146-169) and
+ * Agent._policy (:137-141). Each entry point below names the reference function it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer would add there.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every call returns 0 on success or a negative dqn_status; dqn_last_error() gives
+ *     the message of the calling thread's last failure. No exceptions, no abort().
+ *   - all pointers are DEVICE pointers unless the name ends in _host; buffers are
+ *     caller-owned, contiguous, f32 / i32 / u8. The handle owns its own device state
+ *     (parameters, optimizer moments, replay ring, sum-tree, workspaces).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream. Work is only
+ *     enqueued; nothing synchronises except the *_host getters.
+ *   - one host thread per handle; one process per GPU.
+ */
+#ifndef DQN_HIP_H
+#define DQN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQN_ABI_VERSION 1
+
+typedef enum {
+    DQN_OK = 0,
+    DQN_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    DQN_ERR_HIP = -2,         /* HIP runtime error */
+    DQN_ERR_NOMEM = -3,
+    DQN_ERR_STATE = -4,       /* call sequence error (e.g. PER call on a uniform handle) */
+    DQN_ERR_COMM = -5         /* RCCL error / RCCL not available */
+} dqn_status;
+
+typedef enum { DQN_OPT_ADAM = 0, DQN_OPT_ADAMW = 1 } dqn_optimizer;        /* optax.adam / optax.adamw */
+typedef enum { DQN_PREC_F32 = 0, DQN_PREC_BF16 = 1 } dqn_precision;        /* exact f32 MFMA / bf16 MFMA */
+typedef enum { DQN_NET_ONLINE = 0, DQN_NET_TARGET = 1 } dqn_net;
+typedef enum {                                                              /* dqn_buffer() selectors */
+    DQN_BUF_PARAMS = 0, DQN_BUF_TARGET = 1, DQN_BUF_MU = 2, DQN_BUF_NU = 3, DQN_BUF_GRAD = 4,
+    DQN_BUF_TREE = 5, DQN_BUF_STATES = 6, DQN_BUF_ACTIONS = 7, DQN_BUF_REWARDS = 8,
+    DQN_BUF_OBSERVATIONS = 9, DQN_BUF_DONES = 10,
+    DQN_BUF_BATCH_IDX = 11, DQN_BUF_BATCH_ISW = 12, DQN_BUF_BATCH_TD = 13, DQN_BUF_LOSS = 14
+} dqn_buffer_id;
+
+typedef struct dqn_handle dqn_handle;
+
+/* Mirrors the constants of Test/lunar_lander.py:23-48 plus the net dims of
+ * LunarLander/dddqn.py:19-22 and the PER spec. */
+typedef struct {
+    int32_t obs_dim;          /* D  (9 in the reference: LunarLander/env.py:17)            */
+    int32_t hidden1;          /* H1 (32: dddqn.py:19); multiple of 16                       */
+    int32_t hidden2;          /* H2 (64: dddqn.py:20); multiple of 16                       */
+    int32_t num_actions;      /* A  (4);  1 + A <= 16                                       */
+    int64_t capacity;         /* replay ring size (BUFFER_SIZE, Test/lunar_lander.py:24)    */
+    int32_t use_per;          /* 0: uniform sampling (reference); 1: proportional PER       */
+    int32_t max_batch;        /* largest B any call will use                                */
+    int32_t optimizer;        /* dqn_optimizer                                              */
+    float   lr, b1, b2, eps, weight_decay;   /* optax defaults .9 .999 1e-8 (1e-4 adamw)    */
+    float   gamma;            /* GAMMA, Test/lunar_lander.py:34                             */
+    float   per_alpha;        /* 0.6                                                        */
+    float   per_eps;          /* 1e-6                                                       */
+    float   per_beta;         /* IS exponent used by dqn_update_fused (settable)            */
+    int32_t precision;        /* dqn_precision                                              */
+    uint64_t seed;            /* Philox key for the handle's own draws (fused path)         */
+    int32_t world_size;       /* gradient is divided by this inside the optimizer           */
+    int32_t reserved;
+} dqn_config;
+
+const char *dqn_last_error(void);
+int dqn_abi_version(void);
+void dqn_default_config(dqn_config *cfg);
+
+/* lifetime. Replaces the closure construction in q_agent.py:110-113 + ReplayBuffer.__init__
+ * (General/Base/replay_buffer.py:20-34). */
+int dqn_create(const dqn_config *cfg, dqn_handle **out);
+int dqn_destroy(dqn_handle *h);
+
+/* parameter / optimizer state I/O (flat f32, haiku leaf order: w1 b1 w2 b2 wv bv wa ba,
+ * w is [in,out] row-major). which: DQN_BUF_PARAMS / _TARGET / _MU / _NU / _GRAD. */
+int dqn_param_count(const dqn_handle *h, int64_t *n);
+int dqn_set_params(dqn_handle *h, int which, const float *src, int src_is_host, void *stream);
+int dqn_get_params(dqn_handle *h, int which, float *dst, int dst_is_host, void *stream);
+int dqn_set_opt_count(dqn_handle *h, int32_t count, void *stream);   /* ScaleByAdamState.count */
+int dqn_get_opt_count_host(dqn_handle *h, int32_t *count);           /* synchronises */
+int dqn_buffer(dqn_handle *h, int which, void **ptr, int64_t *nbytes);
+int dqn_set_schedule(dqn_handle *h, float per_beta, float lr, void *stream);
+
+/* ReplayBuffer.add (replay_buffer.py:58-65), vectorised: n rows at consecutive slots
+ * counter % capacity. With use_per the new leaves get the running max priority. */
+int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, const float *r,
+                   const float *s2, const uint8_t *d, int32_t n, void *stream);
+int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter);   /* synchronises */
+
+/* sample_batch (replay_buffer.py:68-85). idx_in != NULL: gather exactly those rows
+ * (reference-parity mode: numba's RNG is opaque, so indices are an explicit input);
+ * idx_in == NULL: idx[k] = (Philox4x32-10(seed, ctr, k, stream 1).x * size) >> 32. */
+int dqn_replay_sample_uniform(dqn_handle *h, int32_t B, uint64_t seed, uint64_t ctr,
+                              const int32_t *idx_in, float *s, int32_t *a, float *r,
+                              float *s2, uint8_t *d, int32_t *idx_out, void *stream);
+
+/* proportional PER (not in the reference). Stratified descent of the
+ * f32 sum-tree, gather, normalised IS weights. */
+int dqn_per_sample(dqn_handle *h, int32_t B, float beta, uint64_t seed, uint64_t ctr,
+                   float *s, int32_t *a, float *r, float *s2, uint8_t *d,
+                   int32_t *idx, float *isw, void *stream);
+/* p_i = (|td_i| + eps)^alpha; duplicates: highest batch position wins; parents
+ * recomputed as left + right. */
+int dqn_per_update(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream);
+int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream);
+
+/* Model.__call__ (LunarLander/dddqn.py:24-34): q[B,A]; feat (optional) = the H2
+ * features of return_features=True (:32-33). */
+int dqn_qnet_forward(dqn_handle *h, int which_net, const float *x, int32_t B,
+                     float *q, float *feat, void *stream);
+
+/* the per-sample arithmetic of compute_q_targets (q_learning_functions.py:55-60) +
+ * Huber loss pieces (:36). d is f32 (after preprocessing :84). Any output may be NULL. */
+int dqn_td_targets(dqn_handle *h, const float *q, const float *next_q, const float *next_q_tm,
+                   const int32_t *a, const float *r, const float *d, const float *isw,
+                   float gamma, int32_t B, float *targets, float *td, float *dq, float *loss,
+                   void *stream);
+
+/* compute_q_targets (q_learning_functions.py:42-64): three forwards + the above. */
+int dqn_q_targets(dqn_handle *h, const float *s, const int32_t *a, const float *r,
+                  const float *s2, const float *d, int32_t B, float *targets, void *stream);
+
+/* compute_loss (q_learning_functions.py:31-39); isw NULL = unweighted. loss: 1 f32. */
+int dqn_loss(dqn_handle *h, const float *s, const float *targets, const float *isw,
+             int32_t B, float *loss, void *stream);
+
+/* train_step (q_learning_functions.py:14-28) in two halves, so that a gradient
+ * all-reduce can sit between them: grads -> handle's DQN_BUF_GRAD (+ loss), then
+ * optimizer.update + apply_updates on the handle's params / moments. */
+int dqn_grads(dqn_handle *h, const float *s, const float *targets, const float *isw,
+              int32_t B, float *loss, void *stream);
+int dqn_optimizer_step(dqn_handle *h, void *stream);
+int dqn_train_step(dqn_handle *h, const float *s, const float *targets, int32_t B, void *stream);
+
+/* Agent._step (q_agent.py:146-169) as one call on the handle's own replay:
+ * sample -> q-targets -> backward -> optimizer -> PER write-back. Replayed from a
+ * hipGraph. With world_size > 1 use the two halves around dqn_allreduce_grads (or a
+ * torch.distributed all_reduce on DQN_BUF_GRAD). */
+int dqn_update_fused(dqn_handle *h, int32_t B, void *stream);
+int dqn_update_backward(dqn_handle *h, int32_t B, void *stream);   /* sample .. grads */
+int dqn_update_apply(dqn_handle *h, int32_t B, void *stream);      /* optimizer + PER write-back */
+
+/* compute_action (q_learning_functions.py:67-73) + Agent._policy (q_agent.py:137-141),
+ * vectorised over n rows: greedy iff eps < U(0,1) else randint(0, A), Philox stream 2. */
+int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, uint64_t seed,
+            uint64_t ctr, int32_t *actions, void *stream);
+
+/* Agent._update_target_model (q_agent.py:143-144) */
+int dqn_sync_target(dqn_handle *h, void *stream);
+
+/* gradient all-reduce for independent per-GPU learners (no counterpart in the
+ * reference). unique_id: the 128-byte ncclUniqueId from rank 0. */
+int dqn_comm_unique_id(void *unique_id_128);
+int dqn_comm_init(dqn_handle *h, const void *unique_id_128, int32_t rank, int32_t world);
+int dqn_allreduce_grads(dqn_handle *h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQN_HIP_H */

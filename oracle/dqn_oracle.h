@@ -1,0 +1,129 @@
+/* oracle/dqn_oracle.h -- CPU restatement of the reference's DDDQN hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under oracle/ may be imported, linked or
+ * executed by the product path (deep-q-learning_amd/, include/). Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as checker.
+ *
+ * PARITY UNPINNED: the reference (hal9000universe/deep-q-learning) holds no
+ * tests, golden vectors or known-answer outputs for this path, its third-party
+ * arithmetic (jax/haiku/optax/numba) is absent here, and its only fixture
+ * (Test/lunar_lander/{params,opt_state}.pickle) is refused by
+ * torch.load(weights_only=True), so it is not read. This file restates the
+ * algorithm from the reference's source text; each function cites file:line.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; no FMA contraction, so
+ * every f32 op below is one IEEE-754 rounding and is reproducible on gfx950).
+ */
+#ifndef DQN_ORACLE_H
+#define DQN_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- counter-based RNG (build spec): Philox4x32-10 ---- */
+/* counter = (ctr_lo, ctr_hi, k, stream), key = (seed_lo, seed_hi) */
+enum { ORC_STREAM_PER = 0, ORC_STREAM_UNIFORM = 1, ORC_STREAM_POLICY = 2, ORC_STREAM_ENV = 3 };
+void  orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float orc_u01(uint32_t x);                 /* (x >> 8) * 2^-24, in [0,1) */
+
+/* ---- deterministic f32 pow: only +,-,*,/ each rounded once (no FMA) ---- */
+float orc_log2_det(float x);               /* x > 0, normal */
+float orc_exp2_det(float y);               /* |y| < 126 */
+float orc_pow_det(float x, float a);       /* x > 0 */
+
+/* ---- replay ring: General/Base/replay_buffer.py:20-65 ---- */
+typedef struct {
+    int64_t  capacity;       /* _buffer_size                      :27 */
+    int32_t  obs_dim;
+    float   *states;         /* (N,D) f32                         :28 */
+    int32_t *actions;        /* (N,) i64 in reference; i32 here   :29 */
+    float   *rewards;        /* (N,) f32                          :30 */
+    float   *observations;   /* (N,D) f32                         :31 */
+    uint8_t *dones;          /* (N,) bool                         :32 */
+    int64_t  counter;        /* _counter                          :33 */
+    int64_t  size;           /* _num_samples                      :34 */
+} orc_replay;
+int  orc_replay_init(orc_replay *rb, int64_t capacity, int32_t obs_dim);
+void orc_replay_free(orc_replay *rb);
+/* add n rows at consecutive slots counter % N   (replay_buffer.py:58-65) */
+void orc_replay_add(orc_replay *rb, const float *s, const int32_t *a, const float *r,
+                    const float *s2, const uint8_t *d, int64_t n, int32_t *slots_out);
+/* idx[k] = (philox(seed,ctr,k,UNIFORM).x * size) >> 32   (replay_buffer.py:77) */
+void orc_uniform_indices(int64_t size, int32_t B, uint64_t seed, uint64_t ctr, int32_t *idx);
+/* 5 gathers (replay_buffer.py:78-84) */
+void orc_replay_gather(const orc_replay *rb, const int32_t *idx, int32_t B,
+                       float *s, int32_t *a, float *r, float *s2, uint8_t *d);
+
+/* ---- PER sum-tree (not in reference; SURVEY.md 8(c2) is the spec) ---- */
+typedef struct {
+    int32_t  L;              /* leaves N = 2^L */
+    int64_t  N;
+    float   *tree;           /* float32[2N], root at 1, leaf i at N+i */
+    float    pmax;           /* running max priority, init 1.0 */
+    float    alpha, eps;     /* p = (|td| + eps)^alpha */
+} orc_per;
+int  orc_per_init(orc_per *t, int32_t L, float alpha, float eps);
+void orc_per_free(orc_per *t);
+/* set leaves[slots] = pmax, recompute touched parents bottom-up */
+void orc_per_add(orc_per *t, const int32_t *slots, int64_t n);
+/* stratified sample; idx clamped to < size; raw IS weight w = (size*p/total)^-beta,
+ * isw = w / max_j w  (all via orc_pow_det, so bit-reproducible) */
+void orc_per_sample(const orc_per *t, int64_t size, int32_t B, float beta,
+                    uint64_t seed, uint64_t ctr, int32_t *idx, float *isw);
+/* p_i = (|td_i|+eps)^alpha; duplicates: highest batch position wins; pmax updated */
+void orc_per_update(orc_per *t, const int32_t *idx, const float *td_abs, int32_t B);
+/* as above but priorities given directly */
+void orc_per_set(orc_per *t, const int32_t *idx, const float *prio, int32_t B);
+
+
+/* ---- dueling Q-network + DDDQN update (f32, k-ordered fmaf chains) ---- */
+/* flat parameter layout (haiku leaf order, w is [in,out] row-major):
+ *   w1[D*H1] b1[H1] w2[H1*H2] b2[H2] wv[H2] bv[1] wa[H2*A] ba[A]          */
+typedef struct { int32_t D, H1, H2, A; } orc_dims;
+int64_t orc_param_count(orc_dims m);
+/* LunarLander/dddqn.py:24-34; h1/h2 (post-ReLU) optional */
+void  orc_forward(orc_dims m, const float *P, const float *x, int32_t B,
+                  float *q, float *h1, float *h2);
+/* General/QLearning/q_learning_functions.py:52-61 (quirks Q3/Q4 kept) */
+void  orc_q_targets(orc_dims m, const float *P, const float *Pt, const float *s,
+                    const int32_t *a, const float *r, const float *s2, const float *d,
+                    float gamma, int32_t B, float *targets,
+                    float *q_out, float *nq_out, float *nt_out, int32_t *astar_out, float *delta_out);
+/* q_learning_functions.py:31-39; isw NULL => unweighted (reference) */
+float orc_loss(orc_dims m, const float *P, const float *s, const float *targets,
+               const float *isw, int32_t B);
+/* gradient of orc_loss wrt P (targets constant), q_learning_functions.py:23 */
+void  orc_grads(orc_dims m, const float *P, const float *s, const float *targets,
+                const float *isw, int32_t B, float *grad, float *loss_out, float *dq_out);
+/* optax adam / adamw; count incremented; b1pow/b2pow are
+ * the running double products b1^t, b2^t (pass 1.0 at t=0) */
+typedef struct { float lr, b1, b2, eps, wd; int32_t adamw; } orc_opt;
+void  orc_adam_step(orc_opt o, float *P, const float *g, float *mu, float *nu,
+                    int32_t *count, double *b1pow, double *b2pow, int64_t n, float grad_scale);
+/* q_learning_functions.py:67-73 + q_agent.py:137-141, vectorised over n rows */
+void  orc_act(orc_dims m, const float *P, const float *s, int32_t n, float epsilon,
+              uint64_t seed, uint64_t ctr, int32_t *actions);
+/* LunarLander/env.py:19-21: out[n,D+1] = append(obs[n,D], step/max_steps) */
+void  orc_obs_augment(const float *obs, const int32_t *step, int32_t max_steps,
+                      int32_t n, int32_t D, float *out);
+
+/* one whole update on the CPU (bench.py cpu_baseline "port"): PER sample -> gather ->
+ * q_targets -> grads -> adam -> PER write-back. Returns loss. */
+typedef struct {
+    orc_dims m; orc_opt opt; float gamma; float beta;
+    orc_replay *rb; orc_per *per;            /* per NULL => uniform sampling */
+    float *P, *Pt, *mu, *nu; int32_t count; double b1pow, b2pow;
+    uint64_t seed, ctr;
+    /* workspace, sized for max batch */
+    int32_t maxB; int32_t *idx, *a; float *isw, *s, *s2, *r, *df, *targets, *delta, *grad; uint8_t *d;
+} orc_learner;
+int   orc_learner_init(orc_learner *l, orc_dims m, orc_opt opt, float gamma, int32_t maxB,
+                       orc_replay *rb, orc_per *per, const float *P0, uint64_t seed);
+void  orc_learner_free(orc_learner *l);
+float orc_learner_update(orc_learner *l, int32_t B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,293 @@
+/* oracle/dqn_oracle_net.c -- CPU restatement: dueling Q-net, double-Q targets, Huber
+ * loss, backward, Adam/AdamW, epsilon-greedy, and a whole-update driver.
+ * TEST INFRASTRUCTURE ONLY (see dqn_oracle.h). PARITY UNPINNED (see dqn_oracle.h).
+ *
+ * f32 throughout. Dot products are k-ordered fmaf chains starting from 0 (the same
+ * arithmetic as gfx950's v_mfma_f32_*_f32), bias added afterwards (hk.Linear: x@w + b).
+ * Everything else is one IEEE rounding per operation (-ffp-contract=off).
+ */
+#include "dqn_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+int64_t orc_param_count(orc_dims m) {
+    return (int64_t)m.D * m.H1 + m.H1 + (int64_t)m.H1 * m.H2 + m.H2 + m.H2 + 1 + (int64_t)m.H2 * m.A + m.A;
+}
+
+typedef struct { int64_t w1, b1, w2, b2, wv, bv, wa, ba; } offs_t;
+static offs_t offsets(orc_dims m) {
+    offs_t o; int64_t p = 0;
+    o.w1 = p; p += (int64_t)m.D * m.H1;  o.b1 = p; p += m.H1;
+    o.w2 = p; p += (int64_t)m.H1 * m.H2; o.b2 = p; p += m.H2;
+    o.wv = p; p += m.H2;                 o.bv = p; p += 1;
+    o.wa = p; p += (int64_t)m.H2 * m.A;  o.ba = p; p += m.A;
+    return o;
+}
+
+/* y[n] = (sum_k x[k]*w[k,n], k ascending, fmaf chain from 0) + b[n] */
+static void linear_row(const float *x, const float *w, const float *b, int K, int N, float *y) {
+    for (int n = 0; n < N; ++n) y[n] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float xk = x[k];
+        const float *wr = w + (int64_t)k * N;
+        for (int n = 0; n < N; ++n) y[n] = fmaf(xk, wr[n], y[n]);
+    }
+    for (int n = 0; n < N; ++n) y[n] = y[n] + b[n];
+}
+
+void orc_forward(orc_dims m, const float *P, const float *x, int32_t B,
+                 float *q, float *h1_out, float *h2_out) {
+    /* LunarLander/dddqn.py:24-31 */
+    offs_t o = offsets(m);
+    float *h1 = (float *)malloc(sizeof(float) * m.H1);
+    float *h2 = (float *)malloc(sizeof(float) * m.H2);
+    float adv[64];
+    for (int32_t i = 0; i < B; ++i) {
+        linear_row(x + (int64_t)i * m.D, P + o.w1, P + o.b1, m.D, m.H1, h1);   /* :25 */
+        for (int j = 0; j < m.H1; ++j) h1[j] = h1[j] > 0.0f ? h1[j] : 0.0f;   /* :26 */
+        linear_row(h1, P + o.w2, P + o.b2, m.H1, m.H2, h2);                    /* :27 */
+        for (int j = 0; j < m.H2; ++j) h2[j] = h2[j] > 0.0f ? h2[j] : 0.0f;   /* :28 */
+        float v;
+        linear_row(h2, P + o.wv, P + o.bv, m.H2, 1, &v);                       /* :29 */
+        linear_row(h2, P + o.wa, P + o.ba, m.H2, m.A, adv);                    /* :30 */
+        float sum = 0.0f;
+        for (int a = 0; a < m.A; ++a) sum = sum + adv[a];
+        const float mean = sum / (float)m.A;
+        for (int a = 0; a < m.A; ++a) q[(int64_t)i * m.A + a] = (v + adv[a]) - mean; /* :31 */
+        if (h1_out) memcpy(h1_out + (int64_t)i * m.H1, h1, sizeof(float) * m.H1);
+        if (h2_out) memcpy(h2_out + (int64_t)i * m.H2, h2, sizeof(float) * m.H2);
+    }
+    free(h1); free(h2);
+}
+
+void orc_q_targets(orc_dims m, const float *P, const float *Pt, const float *s,
+                   const int32_t *a, const float *r, const float *s2, const float *d,
+                   float gamma, int32_t B, float *targets,
+                   float *q_out, float *nq_out, float *nt_out, int32_t *astar_out, float *delta_out) {
+    /* General/QLearning/q_learning_functions.py:52-61 */
+    const int A = m.A;
+    float *q  = (float *)malloc(sizeof(float) * (size_t)B * A);
+    float *nq = (float *)malloc(sizeof(float) * (size_t)B * A);
+    float *nt = (float *)malloc(sizeof(float) * (size_t)B * A);
+    orc_forward(m, P,  s,  B, q,  NULL, NULL);   /* :52 */
+    orc_forward(m, P,  s2, B, nq, NULL, NULL);   /* :53 */
+    orc_forward(m, Pt, s2, B, nt, NULL, NULL);   /* :54 */
+    for (int32_t i = 0; i < B; ++i) {
+        const float *nqi = nq + (int64_t)i * A;
+        int astar = 0;                            /* :55 argmax, first max wins */
+        for (int k = 1; k < A; ++k) if (nqi[k] > nqi[astar]) astar = k;
+        const float qa = q[(int64_t)i * A + a[i]];
+        /* :58  r + (1 - done) * (gamma * next_q_tm[max_action] - q[action])   (quirk Q3) */
+        const float t1 = gamma * nt[(int64_t)i * A + astar];
+        const float t2 = t1 - qa;
+        const float t3 = (1.0f - d[i]) * t2;
+        const float delta = r[i] + t3;
+        /* :59  q + target_val * one_hot(action)                              (quirk Q4) */
+        for (int k = 0; k < A; ++k)
+            targets[(int64_t)i * A + k] = q[(int64_t)i * A + k] + delta * (k == a[i] ? 1.0f : 0.0f);
+        if (astar_out) astar_out[i] = astar;
+        if (delta_out) delta_out[i] = delta;
+    }
+    if (q_out)  memcpy(q_out,  q,  sizeof(float) * (size_t)B * A);
+    if (nq_out) memcpy(nq_out, nq, sizeof(float) * (size_t)B * A);
+    if (nt_out) memcpy(nt_out, nt, sizeof(float) * (size_t)B * A);
+    free(q); free(nq); free(nt);
+}
+
+static inline float huber(float e) {
+    /* optax.huber_loss(delta=1): 0.5*min(|e|,1)^2 + (|e| - min(|e|,1)) */
+    const float ae = fabsf(e);
+    const float qd = ae < 1.0f ? ae : 1.0f;
+    return 0.5f * (qd * qd) + (ae - qd);
+}
+
+float orc_loss(orc_dims m, const float *P, const float *s, const float *targets,
+               const float *isw, int32_t B) {
+    /* q_learning_functions.py:35-36: mean_i sum_a huber(pred - target) */
+    const int A = m.A;
+    float *pred = (float *)malloc(sizeof(float) * (size_t)B * A);
+    orc_forward(m, P, s, B, pred, NULL, NULL);
+    float acc = 0.0f;
+    for (int32_t i = 0; i < B; ++i) {
+        float row = 0.0f;
+        for (int k = 0; k < A; ++k) row = row + huber(pred[(int64_t)i * A + k] - targets[(int64_t)i * A + k]);
+        if (isw) row = isw[i] * row;
+        acc = acc + row;
+    }
+    free(pred);
+    return acc / (float)B;
+}
+
+void orc_grads(orc_dims m, const float *P, const float *s, const float *targets,
+               const float *isw, int32_t B, float *grad, float *loss_out, float *dq_out) {
+    /* jax.grad(compute_loss) (q_learning_functions.py:23), hand-derived:
+     *   dL/dpred = w_i * clip(pred - target, -1, 1) / B
+     *   dueling: dv = sum_a g_a ; dadv_j = g_j - (1/A) sum_a g_a
+     *   relu' = 1 where the activation is > 0, else 0 */
+    const int D = m.D, H1 = m.H1, H2 = m.H2, A = m.A;
+    offs_t o = offsets(m);
+    const int64_t n = orc_param_count(m);
+    float *pred = (float *)malloc(sizeof(float) * (size_t)B * A);
+    float *h1 = (float *)malloc(sizeof(float) * (size_t)B * H1);
+    float *h2 = (float *)malloc(sizeof(float) * (size_t)B * H2);
+    float *dz2 = (float *)malloc(sizeof(float) * H2);
+    float *dz1 = (float *)malloc(sizeof(float) * H1);
+    orc_forward(m, P, s, B, pred, h1, h2);
+    memset(grad, 0, sizeof(float) * (size_t)n);
+    float acc = 0.0f;
+    const float invB = 1.0f / (float)B;
+    for (int32_t i = 0; i < B; ++i) {
+        float g[64], dadv[64];
+        float row = 0.0f, gsum = 0.0f;
+        const float w = isw ? isw[i] : 1.0f;
+        for (int k = 0; k < A; ++k) {
+            const float e = pred[(int64_t)i * A + k] - targets[(int64_t)i * A + k];
+            row = row + huber(e);
+            const float c = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+            g[k] = (w * c) * invB;
+            gsum = gsum + g[k];
+            if (dq_out) dq_out[(int64_t)i * A + k] = g[k];
+        }
+        acc = acc + (isw ? w * row : row);
+        const float dv = gsum;
+        const float gmean = gsum / (float)A;
+        for (int k = 0; k < A; ++k) dadv[k] = g[k] - gmean;
+        const float *h2i = h2 + (int64_t)i * H2, *h1i = h1 + (int64_t)i * H1, *xi = s + (int64_t)i * D;
+        /* heads */
+        for (int j = 0; j < H2; ++j) {
+            grad[o.wv + j] = fmaf(h2i[j], dv, grad[o.wv + j]);
+            for (int k = 0; k < A; ++k)
+                grad[o.wa + (int64_t)j * A + k] = fmaf(h2i[j], dadv[k], grad[o.wa + (int64_t)j * A + k]);
+        }
+        grad[o.bv] = grad[o.bv] + dv;
+        for (int k = 0; k < A; ++k) grad[o.ba + k] = grad[o.ba + k] + dadv[k];
+        /* dh2 = dv*wv^T + dadv*wa^T, through ReLU */
+        for (int j = 0; j < H2; ++j) {
+            float t = P[o.wv + j] * dv;
+            for (int k = 0; k < A; ++k) t = fmaf(P[o.wa + (int64_t)j * A + k], dadv[k], t);
+            dz2[j] = h2i[j] > 0.0f ? t : 0.0f;
+        }
+        /* layer 2 */
+        for (int k = 0; k < H1; ++k) {
+            const float hk = h1i[k];
+            float *gw = grad + o.w2 + (int64_t)k * H2;
+            for (int j = 0; j < H2; ++j) gw[j] = fmaf(hk, dz2[j], gw[j]);
+        }
+        for (int j = 0; j < H2; ++j) grad[o.b2 + j] = grad[o.b2 + j] + dz2[j];
+        for (int k = 0; k < H1; ++k) {
+            const float *wr = P + o.w2 + (int64_t)k * H2;
+            float t = 0.0f;
+            for (int j = 0; j < H2; ++j) t = fmaf(wr[j], dz2[j], t);
+            dz1[k] = h1i[k] > 0.0f ? t : 0.0f;
+        }
+        /* layer 1 */
+        for (int k = 0; k < D; ++k) {
+            const float xk = xi[k];
+            float *gw = grad + o.w1 + (int64_t)k * H1;
+            for (int j = 0; j < H1; ++j) gw[j] = fmaf(xk, dz1[j], gw[j]);
+        }
+        for (int j = 0; j < H1; ++j) grad[o.b1 + j] = grad[o.b1 + j] + dz1[j];
+    }
+    if (loss_out) *loss_out = acc / (float)B;
+    free(pred); free(h1); free(h2); free(dz2); free(dz1);
+}
+
+void orc_adam_step(orc_opt o, float *P, const float *g, float *mu, float *nu,
+                   int32_t *count, double *b1pow, double *b2pow, int64_t n, float grad_scale) {
+    /* optax scale_by_adam -> (adamw: add_decayed_weights) -> scale(-lr) -> apply_updates
+     * (call sites: Test/lunar_lander.py:48, q_learning_functions.py:24-25) */
+    *count += 1;
+    *b1pow *= (double)o.b1;
+    *b2pow *= (double)o.b2;
+    const float c1 = (float)(1.0 - *b1pow), c2 = (float)(1.0 - *b2pow);
+    const float omb1 = 1.0f - o.b1, omb2 = 1.0f - o.b2, neglr = -o.lr;
+    for (int64_t i = 0; i < n; ++i) {
+        const float gi = g[i] * grad_scale;
+        const float m = (o.b1 * mu[i]) + (omb1 * gi);
+        const float v = (o.b2 * nu[i]) + (omb2 * (gi * gi));
+        mu[i] = m; nu[i] = v;
+        const float mhat = m / c1, vhat = v / c2;
+        float u = mhat / (sqrtf(vhat) + o.eps);
+        if (o.adamw) u = u + (o.wd * P[i]);
+        P[i] = P[i] + (neglr * u);
+    }
+}
+
+void orc_act(orc_dims m, const float *P, const float *s, int32_t n, float epsilon,
+             uint64_t seed, uint64_t ctr, int32_t *actions) {
+    /* q_agent.py:137-141: greedy iff epsilon < U(0,1) else randint(0, A);
+     * q_learning_functions.py:70: argmax over the (1,A) output */
+    float *q = (float *)malloc(sizeof(float) * (size_t)n * m.A);
+    orc_forward(m, P, s, n, q, NULL, NULL);
+    for (int32_t i = 0; i < n; ++i) {
+        uint32_t c[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)i, ORC_STREAM_POLICY };
+        uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) }, out[4];
+        orc_philox4x32_10(c, key, out);
+        if (epsilon < orc_u01(out[0])) {
+            int best = 0;
+            for (int k = 1; k < m.A; ++k) if (q[(int64_t)i * m.A + k] > q[(int64_t)i * m.A + best]) best = k;
+            actions[i] = best;
+        } else {
+            actions[i] = (int32_t)(((uint64_t)out[1] * (uint64_t)m.A) >> 32);
+        }
+    }
+    free(q);
+}
+
+void orc_obs_augment(const float *obs, const int32_t *step, int32_t max_steps,
+                     int32_t n, int32_t D, float *out) {
+    /* LunarLander/env.py:19-21: append(observation, step/max_steps).astype(float32)
+     * (python float division is f64, then cast) */
+    for (int32_t i = 0; i < n; ++i) {
+        memcpy(out + (int64_t)i * (D + 1), obs + (int64_t)i * D, sizeof(float) * D);
+        out[(int64_t)i * (D + 1) + D] = (float)((double)step[i] / (double)max_steps);
+    }
+}
+
+/* ------------------------------------------------------------ whole update */
+int orc_learner_init(orc_learner *l, orc_dims m, orc_opt opt, float gamma, int32_t maxB,
+                     orc_replay *rb, orc_per *per, const float *P0, uint64_t seed) {
+    memset(l, 0, sizeof(*l));
+    l->m = m; l->opt = opt; l->gamma = gamma; l->beta = 0.4f; l->rb = rb; l->per = per;
+    l->maxB = maxB; l->seed = seed; l->ctr = 0; l->count = 0; l->b1pow = 1.0; l->b2pow = 1.0;
+    const int64_t n = orc_param_count(m);
+    l->P = (float *)malloc(sizeof(float) * n);  l->Pt = (float *)malloc(sizeof(float) * n);
+    l->mu = (float *)calloc(n, sizeof(float));  l->nu = (float *)calloc(n, sizeof(float));
+    l->grad = (float *)malloc(sizeof(float) * n);
+    memcpy(l->P, P0, sizeof(float) * n); memcpy(l->Pt, P0, sizeof(float) * n);
+    l->idx = (int32_t *)malloc(sizeof(int32_t) * maxB); l->a = (int32_t *)malloc(sizeof(int32_t) * maxB);
+    l->isw = (float *)malloc(sizeof(float) * maxB);
+    l->s = (float *)malloc(sizeof(float) * (size_t)maxB * m.D); l->s2 = (float *)malloc(sizeof(float) * (size_t)maxB * m.D);
+    l->r = (float *)malloc(sizeof(float) * maxB); l->df = (float *)malloc(sizeof(float) * maxB);
+    l->d = (uint8_t *)malloc(maxB);
+    l->targets = (float *)malloc(sizeof(float) * (size_t)maxB * m.A);
+    l->delta = (float *)malloc(sizeof(float) * maxB);
+    return 0;
+}
+
+void orc_learner_free(orc_learner *l) {
+    free(l->P); free(l->Pt); free(l->mu); free(l->nu); free(l->grad); free(l->idx); free(l->a);
+    free(l->isw); free(l->s); free(l->s2); free(l->r); free(l->df); free(l->d); free(l->targets); free(l->delta);
+    memset(l, 0, sizeof(*l));
+}
+
+float orc_learner_update(orc_learner *l, int32_t B) {
+    /* q_agent.py:146-169 (_step): sample -> preprocessing -> q_targets -> train_step */
+    float loss = 0.0f;
+    if (l->per) orc_per_sample(l->per, l->rb->size, B, l->beta, l->seed, l->ctr, l->idx, l->isw);
+    else        orc_uniform_indices(l->rb->size, B, l->seed, l->ctr, l->idx);
+    l->ctr += 1;
+    orc_replay_gather(l->rb, l->idx, B, l->s, l->a, l->r, l->s2, l->d);
+    for (int32_t i = 0; i < B; ++i) l->df[i] = l->d[i] ? 1.0f : 0.0f;   /* preprocessing :84 */
+    orc_q_targets(l->m, l->P, l->Pt, l->s, l->a, l->r, l->s2, l->df, l->gamma, B,
+                  l->targets, NULL, NULL, NULL, NULL, l->delta);
+    orc_grads(l->m, l->P, l->s, l->targets, l->per ? l->isw : NULL, B, l->grad, &loss, NULL);
+    orc_adam_step(l->opt, l->P, l->grad, l->mu, l->nu, &l->count, &l->b1pow, &l->b2pow,
+                  orc_param_count(l->m), 1.0f);
+    if (l->per) {
+        for (int32_t i = 0; i < B; ++i) l->delta[i] = fabsf(l->delta[i]);
+        orc_per_update(l->per, l->idx, l->delta, B);
+    }
+    return loss;
+}
