@@ -1,0 +1,307 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libdqn_hip.so), against
+the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for integer / index / tree work (and for everything the spec makes
+reproducible: Philox draws, deterministic pow, Adam); FP network outputs within 1e-5 of the
+f64 oracle (north_star tolerance), stated per assert.
+"""
+import numpy as np
+import pytest
+
+import _oracle as oc
+from _oracle import onp
+from test_oracle import CFGS, make_batch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = ATOL = 1e-5          # north_star: "FP outputs within 1e-5 on fixed seeds/minibatches"
+
+
+@pytest.fixture(scope="module")
+def dq(torch_cuda):
+    import deep_q_learning_amd as pkg
+    return pkg
+
+
+def mk(dq, dims, **kw):
+    cfg = dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], **kw)
+    return dq.Engine(cfg)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_params(dims, seed):
+    P = onp.init_params(dims, seed)
+    return (P + 0.05 * np.random.default_rng(seed + 100).standard_normal(P.size)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------- forward
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg1", 1), ("cfg1", 37), ("cfg2", 1024), ("cfg3", 8192), ("cfg2", 100)])
+def test_forward_parity(dq, name, B):
+    """Model.__call__ (LunarLander/dddqn.py:24-34)"""
+    dims = CFGS[name]
+    e = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 0), rand_params(dims, 1)
+    e.set_params(P); e.set_params(Pt, dq._lib.BUF_TARGET)
+    x = np.random.default_rng(2).standard_normal((B, dims[0])).astype(np.float32)
+    q, feat = e.forward(x, return_features=True)
+    qt = e.forward(x, target=True)
+    q64, _, h64 = onp.forward(P, x, dims, np.float64, return_hidden=True)
+    assert np.allclose(host(q), q64, rtol=RTOL, atol=ATOL)
+    assert np.allclose(host(feat), h64, rtol=RTOL, atol=ATOL)
+    assert np.allclose(host(qt), onp.forward(Pt, x, dims, np.float64), rtol=RTOL, atol=ATOL)
+    # the f32 MFMA chain is the same k-ordered fmaf chain as the C oracle: expect bit equality
+    qc, _, h2c = oc.forward(dims, P, x)
+    assert np.array_equal(host(q), qc)
+    assert np.array_equal(host(feat), h2c)
+    # round trip of the parameter I/O
+    assert np.array_equal(e.get_params(host=True), P)
+    e.close()
+
+
+# ------------------------------------------------------------------------- targets
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 512)])
+def test_q_targets_parity(dq, name, B):
+    """compute_q_targets (q_learning_functions.py:42-64) incl. quirks Q3/Q4 and argmax ties"""
+    dims = CFGS[name]
+    e = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 3), rand_params(dims, 4)
+    P[onp.param_count(*dims) - dims[3]:] = 0.0           # ba = 0 -> exact ties possible on the s2=0 row
+    e.set_params(P); e.set_params(Pt, dq._lib.BUF_TARGET)
+    s, a, r, s2, d = make_batch(dims, B, 5)
+    t = host(e.q_targets(s, a, r, s2, d))
+    ref = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64, full=True)
+    c = oc.q_targets(dims, P, Pt, s, a, r, s2, d, 0.99)
+    assert np.allclose(t, ref["targets"], rtol=RTOL, atol=ATOL * 10)   # |target| reaches 100 (terminal rewards)
+    assert np.array_equal(t, c["targets"])                              # bit-exact vs the f32 restatement
+    i = np.arange(B); term = d > 0
+    assert term.sum() >= B // 10
+    assert np.array_equal(t[i, a][term], (c["q"][i, a] + r)[term])     # quirk Q3
+    # the per-sample arithmetic alone (dqn_td_targets) with IS weights
+    isw = np.random.default_rng(6).uniform(0.1, 1, B).astype(np.float32)
+    out = e.td_targets(c["q"], c["nq"], c["nt"], a, r, d, isw=isw)
+    assert np.array_equal(host(out["targets"]), c["targets"])
+    assert np.array_equal(host(out["td"]), c["delta"])
+    _, L64, g64 = onp.grads(P, s, ref["targets"], dims, isw, np.float64)
+    assert np.allclose(host(out["dq"]), g64, rtol=1e-4, atol=1e-7)
+    assert abs(host(out["loss"])[0] - L64) <= 1e-5 * max(1, abs(L64))
+    e.close()
+
+
+# ----------------------------------------------------------------- loss / gradients
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 8192), ("cfg1", 50)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_loss_and_grads_parity(dq, name, B, weighted):
+    """compute_loss (:31-39) and jax.grad(compute_loss) (:23)"""
+    dims = CFGS[name]
+    e = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 7), rand_params(dims, 8)
+    e.set_params(P)
+    s, a, r, s2, d = make_batch(dims, B, 9)
+    r = np.clip(r, -3, 3)
+    targets = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64).astype(np.float32)
+    isw = np.random.default_rng(10).uniform(0.2, 1, B).astype(np.float32) if weighted else None
+    g64, L64, _ = onp.grads(P, s, targets, dims, isw, np.float64)
+    L = host(e.loss(s, targets, isw))[0]
+    assert abs(L - L64) <= 1e-5 * max(1.0, abs(L64))
+    g, Lg = e.grads(s, targets, isw)
+    g = host(g)
+    assert abs(host(Lg)[0] - L64) <= 1e-5 * max(1.0, abs(L64))
+    scale = np.abs(g64).max()
+    assert np.max(np.abs(g - g64)) <= 1e-5 * max(scale, 1e-3), (np.max(np.abs(g - g64)), scale)
+    e.close()
+
+
+# ----------------------------------------------------------------------- optimizer
+@pytest.mark.parametrize("opt", ["adamw", "adam"])
+def test_train_step_parity(dq, opt):
+    """train_step (:14-28): 3 consecutive updates; Adam arithmetic bit-exact given equal grads"""
+    dims = CFGS["cfg1"]
+    B = 64
+    lr = 2e-4 if opt == "adamw" else 1e-4
+    e = mk(dq, dims, max_batch=B, optimizer=opt, lr=lr)
+    P0, Pt = rand_params(dims, 11), rand_params(dims, 12)
+    e.set_params(P0)
+    P64, mu64, nu64, cnt = P0.astype(np.float64), np.zeros(P0.size), np.zeros(P0.size), 0
+    for it in range(3):
+        s, a, r, s2, d = make_batch(dims, B, 13 + it)
+        r = np.clip(r, -3, 3)
+        targets = onp.q_targets(P64, Pt, s, a, r, s2, d, 0.99, dims, np.float64).astype(np.float32)
+        g64, _, _ = onp.grads(P64, s, targets, dims, None, np.float64)
+        P64, mu64, nu64, cnt = onp.adam_step(P64, g64, mu64, nu64, cnt, lr, adamw=(opt == "adamw"), dtype=np.float64)
+        e.train_step(s, targets)
+    assert e.opt_count() == 3
+    assert np.allclose(e.get_params(host=True), P64, rtol=1e-5, atol=1e-6)
+    assert np.allclose(e.get_params(dq._lib.BUF_MU, host=True), mu64, rtol=1e-4, atol=1e-8)
+    # bit-exact optimizer: feed the GPU's own gradient to the C oracle's Adam
+    e2 = mk(dq, dims, max_batch=B, optimizer=opt, lr=lr)
+    e2.set_params(P0)
+    s, a, r, s2, d = make_batch(dims, B, 20)
+    targets = onp.q_targets(P0, Pt, s, a, r, s2, d, 0.99, dims, np.float64).astype(np.float32)
+    g, _ = e2.grads(s, targets)
+    g = host(g)
+    e2.optimizer_step()
+    copt = oc.Opt(lr, 0.9, 0.999, 1e-8, 1e-4, int(opt == "adamw"))
+    Pc, muc, nuc, *_ = oc.adam_step(copt, P0, g, np.zeros_like(P0), np.zeros_like(P0), 0, 1.0, 1.0)
+    assert np.array_equal(e2.get_params(host=True), Pc)
+    assert np.array_equal(e2.get_params(dq._lib.BUF_MU, host=True), muc)
+    assert np.array_equal(e2.get_params(dq._lib.BUF_NU, host=True), nuc)
+    # the refreshed packed weights are what the next forward uses
+    x = np.random.default_rng(21).standard_normal((B, dims[0])).astype(np.float32)
+    assert np.array_equal(host(e2.forward(x)), oc.forward(dims, Pc, x)[0])
+    e.close(); e2.close()
+
+
+def test_resume_from_opt_count(dq):
+    """opt_state round trip: count=t restores the bias-correction powers"""
+    dims = CFGS["cfg1"]
+    e = mk(dq, dims, max_batch=64)
+    P0 = rand_params(dims, 30)
+    rng = np.random.default_rng(31)
+    mu = (rng.standard_normal(P0.size) * 1e-3).astype(np.float32); nu = (rng.random(P0.size) * 1e-5).astype(np.float32)
+    g = (rng.standard_normal(P0.size) * 1e-2).astype(np.float32)
+    e.set_params(P0); e.set_params(mu, dq._lib.BUF_MU); e.set_params(nu, dq._lib.BUF_NU); e.set_params(g, dq._lib.BUF_GRAD)
+    e.set_opt_count(1000)
+    e.optimizer_step()
+    copt = oc.Opt(2e-4, 0.9, 0.999, 1e-8, 1e-4, 1)
+    Pc, *_ = oc.adam_step(copt, P0, g, mu, nu, 1000, np.float32(0.9).astype(np.float64) ** 1000,
+                          np.float32(0.999).astype(np.float64) ** 1000)
+    assert np.allclose(e.get_params(host=True), Pc, rtol=1e-6, atol=1e-8)   # host pow() vs numpy: <= 1 ulp in c1/c2
+    assert e.opt_count() == 1001
+    e.close()
+
+
+# --------------------------------------------------------------------- replay ring
+def test_replay_ring_and_uniform_sample_bitexact(dq):
+    """ReplayBuffer.add (:58-65) incl. wrap, sample_batch gathers (:77-84)"""
+    N, dims = 1000, CFGS["cfg1"]
+    D = dims[0]
+    e = mk(dq, dims, capacity=N, max_batch=256)
+    cr = oc.CReplay(N, D)
+    rng = np.random.default_rng(40)
+    for n in (1, 255, 256, 300, 256, 77):                 # wraps once
+        s = rng.standard_normal((n, D)).astype(np.float32); s2 = rng.standard_normal((n, D)).astype(np.float32)
+        a = rng.integers(0, 4, n).astype(np.int32); r = rng.standard_normal(n).astype(np.float32)
+        d = (rng.random(n) < 0.2)
+        cr.add(s, a, r, s2, d); e.replay_add(s, a, r, s2, d)
+    assert e.replay_size() == (cr.size, cr.rb.counter) == (N, 1145)
+    L = dq._lib
+    import torch
+    got = (e.buffer(L.BUF_STATES).view(N, D), e.buffer(L.BUF_ACTIONS, torch.int32), e.buffer(L.BUF_REWARDS),
+           e.buffer(L.BUF_OBSERVATIONS).view(N, D), e.buffer(L.BUF_DONES, torch.uint8))
+    for x, y in zip(got, cr.arrays()):
+        assert np.array_equal(host(x), y)
+    for B, seed, ctr in ((64, 1, 0), (256, 2, 7)):
+        batch, idx = e.sample_uniform(B, seed, ctr)
+        want_idx = oc.uniform_indices(cr.size, B, seed, ctr)
+        assert np.array_equal(host(idx), want_idx)
+        for x, y in zip(batch, cr.gather(want_idx)):
+            assert np.array_equal(host(x), y)
+    given = rng.integers(0, N, 100).astype(np.int32)         # reference-parity mode: explicit indices
+    batch, idx = e.sample_uniform(100, idx=given)
+    for x, y in zip(batch, cr.gather(given)):
+        assert np.array_equal(host(x), y)
+    e.close()
+
+
+# ------------------------------------------------------------------------------ PER
+@pytest.mark.parametrize("L_,n_add,B", [(10, 700, 64), (14, 16384, 1024), (20, 300000, 1024)])
+def test_per_bitexact(dq, L_, n_add, B):
+    """sum-tree insert / stratified sample / IS weights / write-back with duplicates: idx, weights and
+    the whole tree bit-identical to the CPU restatement"""
+    dims = CFGS["cfg3"]
+    D = dims[0]
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=max(B, 4096))
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    rng = np.random.default_rng(50 + L_)
+    done = 0
+    while done < n_add:
+        n = min(4096, n_add - done)
+        s = rng.standard_normal((n, D)).astype(np.float32); s2 = rng.standard_normal((n, D)).astype(np.float32)
+        a = rng.integers(0, 2, n).astype(np.int32); r = rng.standard_normal(n).astype(np.float32); d = rng.random(n) < 0.1
+        ct.add(cr.add(s, a, r, s2, d)); e.replay_add(s, a, r, s2, d)
+        done += n
+    tree = lambda: host(e.buffer(dq._lib.BUF_TREE))
+    assert np.array_equal(tree(), ct.tree)
+    # give the leaves distinct priorities
+    idx0 = rng.permutation(n_add)[: min(n_add, 50000)].astype(np.int32)
+    for k in range(0, len(idx0), 4096):
+        pr = (rng.random(len(idx0[k:k + 4096])) + 0.01).astype(np.float32)
+        ct.set(idx0[k:k + 4096], pr); e.per_set(idx0[k:k + 4096], pr)
+    assert np.array_equal(tree(), ct.tree)
+    for it in range(3):
+        beta = 0.4 + 0.2 * it
+        batch, idx, isw = e.per_sample(B, beta, seed=9, ctr=it)
+        ci, cw = ct.sample(cr.size, B, beta, 9, it)
+        assert np.array_equal(host(idx), ci)
+        assert np.array_equal(host(isw).view(np.uint32), cw.view(np.uint32))
+        for x, y in zip(batch, cr.gather(ci)):
+            assert np.array_equal(host(x), y)
+        td = (np.abs(rng.standard_normal(B)) * 2).astype(np.float32)
+        upd = ci.copy(); upd[3] = upd[B - 1]; upd[10:20] = upd[10]          # duplicates
+        ct.update(upd, td); e.per_update(upd, td)
+        t = tree()
+        assert np.array_equal(t.view(np.uint32), ct.tree.view(np.uint32))
+    k = np.arange(1, N)
+    assert np.array_equal(t[k], t[2 * k] + t[2 * k + 1])                     # size-independent invariant
+    e.close()
+
+
+# ---------------------------------------------------------------------------- policy
+def test_act_parity(dq):
+    """compute_action (:67-73) + Agent._policy (q_agent.py:137-141), vectorised"""
+    dims = CFGS["cfg2"]
+    e = mk(dq, dims, max_batch=4096)
+    P = rand_params(dims, 60)
+    e.set_params(P)
+    s = np.random.default_rng(61).standard_normal((4096, dims[0])).astype(np.float32)
+    for eps in (0.0, 0.15, 1.0):
+        assert np.array_equal(host(e.act(s, eps, seed=5, ctr=2)), oc.act(dims, P, s, eps, 5, 2))
+    e.close()
+
+
+# ------------------------------------------------------------------ the fused update
+@pytest.mark.parametrize("name,B,per", [("cfg1", 64, False), ("cfg1", 64, True), ("cfg2", 1024, True), ("cfg3", 2048, True)])
+def test_fused_update_tracks_oracle(dq, name, B, per):
+    """Agent._step (q_agent.py:146-169) as dqn_update_fused, 4 consecutive updates (graph replays) with a
+    target sync in between, against the C oracle's whole-update driver on the same replay contents.
+    Indices / IS weights must match exactly while priorities agree; parameters within 1e-5."""
+    import torch
+    dims = CFGS[name]
+    D, A = dims[0], dims[3]
+    L_ = 12
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=1e-3)
+    cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
+    s, a, r, s2, d = make_batch(dims, 3000, 70, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    for k in range(0, 3000, 1000):
+        sl = slice(k, k + 1000)
+        slots = cr.add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)
+        if per:
+            ct.add(slots)
+        e.replay_add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)
+    P0 = rand_params(dims, 71)
+    e.set_params(P0); e.set_params(P0, dq._lib.BUF_TARGET)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 77, beta=0.4)
+    with torch.cuda.stream(e.stream):
+        for it in range(4):
+            Lc = lrn.update(B)
+            e.update(B)
+            e.stream.synchronize()
+            Lg = host(e.last_loss())[0]
+            assert abs(Lg - Lc) <= 2e-5 * max(1.0, abs(Lc)), (it, Lg, Lc)
+            idx = host(e.buffer(dq._lib.BUF_BATCH_IDX, torch.int32))[:B]
+            assert np.array_equal(idx, np.ctypeslib.as_array(lrn.l.idx, shape=(B,))), it
+            if it == 1:
+                e.sync_target(); lrn.sync_target()
+    Pg = e.get_params(host=True)
+    assert np.max(np.abs(Pg - lrn.params)) <= 1e-5, np.max(np.abs(Pg - lrn.params))
+    assert e.opt_count() == 4
+    if per:
+        # priorities come from |delta| (FP, 1e-5-level differences) -> tree close, not bitwise
+        assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    e.close()
