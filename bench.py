@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- DDDQN inner training loop on MI355X: grad-updates/sec + env-steps/sec.
+
+Workload (BASELINE.json configs[1]): LunarLander shape (obs 8, act 4), 256 vectorised synthetic envs,
+proportional PER over a 2^20-transition ring resident in HBM, batch 1024, dueling MLP 8-256-256-{1,4},
+AdamW. One "step" = the reference's inner loop at train_frequency=4 (Test/lunar_lander.py:30,
+q_agent.py:176-187): 4 vector env steps (act -> synthetic transition -> replay.add, 1024 env-steps)
+followed by one Agent._step (PER sample -> double-Q targets -> Huber grad -> AdamW -> priority write-back).
+Inputs are synthetic and already resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: independent learners (own envs, ring, tree, minibatch), one gradient all-reduce (RCCL) per
+update; value = minibatch updates of all ranks per second (weak scaling, global batch N*1024).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H1, H2, A = 8, 256, 256, 4
+LOG2N = 20
+B = 1024
+N_ENVS = 256
+TRAIN_FREQ = 4            # Test/lunar_lander.py:30
+P_DONE = 0.01
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_cost(name, L, n_params):
+    """(bound, units per launch) -- SURVEY.md 8(d) per-unit figures x units per launch.
+    bytes for HBM-bound kernels, FLOP for MFMA-bound ones."""
+    F = 2 * (D * H1 + H1 * H2 + H2 * (1 + A))
+    if name == "per_sample":
+        return "hbm", (4 * L + 16 * D + 26) * B
+    if name == "per_update":
+        return "hbm", (8 * L + 12) * B
+    if name == "per_add":
+        return "hbm", (8 * L + 4) * N_ENVS
+    if name == "adam":
+        return "hbm", 28 * n_params
+    if name == "replay_add":
+        return "hbm", 2 * (8 * D + 9) * N_ENVS
+    if name == "synth_env":
+        return "hbm", (4 * D + 5) * N_ENVS
+    if name == "act_policy":
+        return "hbm", (4 * A + 4) * N_ENVS
+    if name == "qnet_fwd_x3":
+        return "mfma", 3 * F * B
+    if name == "act_qnet_fwd":
+        return "mfma", F * N_ENVS
+    if name == "td_bwd_rows":
+        return "mfma", (2 * (1 + A) * H2 + 2 * H1 * H2) * B
+    if name == "dw":
+        return "mfma", 2 * B * (D * H1 + H1 * H2 + H2 * (1 + A))
+    return "hbm", 0
+
+
+def prefill(eng, gen):
+    """ring full (2^20 transitions) with SURVEY.md 8(d)'s synthetic distribution, priorities U(0,1)^0.6"""
+    N = 1 << LOG2N
+    chunk = 1 << 16
+    dev = eng.device
+    for k in range(0, N, chunk):
+        s = torch.randn(chunk, D, device=dev, generator=gen)
+        s2 = torch.randn(chunk, D, device=dev, generator=gen)
+        a = torch.randint(0, A, (chunk,), device=dev, generator=gen, dtype=torch.int32)
+        d = torch.rand(chunk, device=dev, generator=gen) < P_DONE
+        r = torch.randn(chunk, device=dev, generator=gen)
+        sign = torch.where(torch.rand(chunk, device=dev, generator=gen) < 0.5, -100.0, 100.0)
+        r = torch.where(d, sign, r)
+        eng.replay_add(s, a, r, s2, d)
+    for k in range(0, N, chunk):
+        idx = torch.arange(k, k + chunk, device=dev, dtype=torch.int32)
+        pr = torch.rand(chunk, device=dev, generator=gen).clamp_min(1e-4) ** 0.6
+        eng.per_set(idx, pr)
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle's plain-C restatement (oracle/, kind "port") timed on this host, single thread, on a
+    bounded sample of the same workload: same shapes, ring 2^20, same step definition."""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import _oracle as oc
+    from _oracle import onp
+    dims = (D, H1, H2, A)
+    N = 1 << LOG2N
+    rng = np.random.default_rng(0)
+    rb, per = oc.CReplay(N, D), oc.CPer(LOG2N)
+    chunk = 1 << 18
+    for k in range(0, N, chunk):
+        s = rng.standard_normal((chunk, D), dtype=np.float32); s2 = rng.standard_normal((chunk, D), dtype=np.float32)
+        a = rng.integers(0, A, chunk).astype(np.int32); d = rng.random(chunk) < P_DONE
+        r = np.where(d, np.where(rng.random(chunk) < 0.5, -100.0, 100.0), rng.standard_normal(chunk)).astype(np.float32)
+        slots = rb.add(s, a, r, s2, d)
+        per.set(slots, (np.maximum(rng.random(chunk), 1e-4) ** 0.6).astype(np.float32))
+    lrn = oc.CLearner(dims, oc.Opt(2e-4, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, rb, per, onp.init_params(dims, 0), 0)
+    obs = rng.standard_normal((N_ENVS, D), dtype=np.float32)
+    env_ctr = 0
+
+    def step():
+        nonlocal env_ctr
+        for _ in range(TRAIN_FREQ):
+            env_ctr = lrn.actor_step(obs, 0.15, P_DONE, env_ctr)
+        lrn.update(B)
+
+    step()                                   # warm-up
+    t0 = time.perf_counter(); step(); t1 = time.perf_counter() - t0
+    n = int(min(max(seconds / max(t1, 1e-6), 3), 2000))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "grad-updates/sec", "cores": 1, "kind": "port",
+            "sample": f"{n} steps (4x256 env-steps + 1 update of B=1024 each) of the same workload in {dt:.1f} s, "
+                      f"plain-C oracle (oracle/dqn_oracle_*.c, gcc -O3 -mavx2 -mfma), 1 thread of {os.cpu_count()} host cores",
+            "env_steps_per_sec": n * N_ENVS * TRAIN_FREQ / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import deep_q_learning_amd as dq
+    L = dq._lib
+    cfg = dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << LOG2N, use_per=True,
+                          max_batch=B, optimizer="adamw", lr=2e-4, gamma=0.99, seed=1000 + rank, world_size=world)
+    eng = dq.Engine(cfg)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    gen = torch.Generator(device=eng.device); gen.manual_seed(1234 + rank)
+    # haiku-style init (TruncatedNormal(1/sqrt(fan_in)), b=0), identical on every rank
+    P0 = torch.empty(eng.param_count)
+    g0 = torch.Generator().manual_seed(0)
+    o = 0
+    for (k, n) in ((D, H1), (H1, H2), (H2, 1), (H2, A)):
+        w = torch.empty(k * n); torch.nn.init.trunc_normal_(w, std=1.0 / k ** 0.5, a=-2.0 / k ** 0.5, b=2.0 / k ** 0.5, generator=g0)
+        P0[o:o + k * n] = w; o += k * n
+        P0[o:o + n] = 0; o += n
+    eng.set_params(P0); eng.set_params(P0, L.BUF_TARGET)
+    prefill(eng, gen)
+    eng.env_reset(torch.randn(N_ENVS, D, device=eng.device, generator=gen), P_DONE)
+    eng.set_epsilon(0.15)                                    # MIN_EPSILON, Test/lunar_lander.py:33
+    grad = eng.buffer(L.BUF_GRAD) if world > 1 else None
+    st = eng.stream
+
+    def step():
+        for _ in range(TRAIN_FREQ):
+            eng.actor_step(st)
+        if world > 1:
+            eng.update_backward(B, st)
+            dist.all_reduce(grad)                            # RCCL, sum; /world is inside the optimizer
+            eng.update_apply(B, st)
+        else:
+            eng.update(B, st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(st):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=eng.device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+        # update-only and actor-only rates (same run, extra information)
+        barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if world > 1:
+                eng.update_backward(B, st); dist.all_reduce(grad); eng.update_apply(B, st)
+            else:
+                eng.update(B, st)
+        barrier(); dt_upd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.actor_step(st)
+        barrier(); dt_act = time.perf_counter() - t0
+
+        # live per-kernel timing with HIP events on the launch stream (rank 0 of N=1 is enough)
+        kern = {}
+        if rank == 0:
+            for _ in range(args.profile_steps):
+                eng.profile_begin(st)
+                eng.actor_step(st)
+                eng.update_backward(B, st); eng.update_apply(B, st)
+                for name, ms in eng.profile_end(st):
+                    kern.setdefault(name, []).append(ms)
+    loss = float(eng.last_loss().item())
+    assert np.isfinite(loss), "non-finite loss"
+
+    if rank == 0:
+        per_step = {}
+        for name, v in kern.items():
+            launches = TRAIN_FREQ if name in ("act_qnet_fwd", "act_policy", "synth_env", "replay_add", "per_add") else 1
+            bound, units = algorithmic_cost(name, LOG2N, eng.param_count)
+            avg_ms = float(np.median(v))
+            ach = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12) if avg_ms > 0 else 0.0
+            peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TFLOPS
+            per_step[name] = {"bound": bound, "avg_us": avg_ms * 1e3, "launches_per_step": launches,
+                              "achieved": ach, "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                              "frac": ach / peak}
+        dom = max(per_step, key=lambda k: per_step[k]["avg_us"] * per_step[k]["launches_per_step"])
+        roof = {k: per_step[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+        roof.update({"kernel": dom, "avg_us": per_step[dom]["avg_us"], "traffic": None,
+                     "timing": "HIP events around each eager launch on the launch stream, median of "
+                               f"{args.profile_steps} (event overhead included); rocprofv3 summary in profiles/"})
+        out = {
+            "metric": "grad-updates/sec", "value": world * args.steps / dt, "unit": "grad-updates/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LunarLander-v2 shape, 256 vectorised synthetic envs, PER batch=1024, 2x256 dueling MLP "
+                                   "(BASELINE.json configs[1]); step = 4 vector env steps (1024 env-steps) + 1 grad update",
+                       "obs_dim": D, "num_actions": A, "hidden": [H1, H2], "batch": B, "global_batch": B * world,
+                       "n_envs_per_gpu": N_ENVS, "replay_capacity": 1 << LOG2N, "per": True, "optimizer": "adamw",
+                       "train_frequency": TRAIN_FREQ, "parallelism": f"dp{world} independent learners + grad all-reduce"},
+            "env_steps_per_sec": world * args.steps * N_ENVS * TRAIN_FREQ / dt,
+            "update_only_per_sec": world * args.steps / dt_upd,
+            "actor_only_env_steps_per_sec": world * args.steps * N_ENVS / dt_act,
+            "final_loss": loss,
+            "roofline": roof,
+            "kernels": per_step,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

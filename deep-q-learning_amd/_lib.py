@@ -13,7 +13,8 @@ OPT_ADAM, OPT_ADAMW = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
- BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS) = range(15)
+ BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,
+ BUF_ENV_ACTIONS) = range(17)
 
 
 class DqnConfig(C.Structure):
@@ -57,6 +58,11 @@ SIGNATURES = {
     "dqn_update_apply": [_P, _I32, _P],
     "dqn_act": [_P, _P, _I32, _F, _U64, _U64, _P, _P],
     "dqn_sync_target": [_P, _P],
+    "dqn_set_epsilon": [_P, _F, _P],
+    "dqn_env_reset": [_P, _P, _I32, _F, _P],
+    "dqn_actor_step": [_P, _I32, _P],
+    "dqn_profile_begin": [_P, _P],
+    "dqn_profile_end": [_P, _P, _P, _I32, _P, _I32, C.POINTER(_I32)],
     "dqn_comm_unique_id": [_P],
     "dqn_comm_init": [_P, _P, _I32, _I32],
     "dqn_allreduce_grads": [_P, _P],

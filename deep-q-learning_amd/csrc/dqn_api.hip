@@ -42,7 +42,7 @@ extern "C" void dqn_default_config(dqn_config *c) {
 }
 
 // ------------------------------------------------------------------------------ handle
-struct GraphSet { hipGraphExec_t fused = nullptr, bwd = nullptr, apply = nullptr; };
+struct GraphSet { hipGraphExec_t fused = nullptr, bwd = nullptr, apply = nullptr, actor = nullptr; };
 
 // RCCL entry points, resolved lazily so the library loads without librccl
 struct NcclId { char b[128]; };   // ncclUniqueId (passed by value to ncclCommInitRank)
@@ -75,6 +75,12 @@ struct dqn_handle {
     float *q = nullptr, *nq = nullptr, *nt = nullptr;
     float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
+    float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
+    float p_done = 0.01f;
+    // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
+    bool profiling = false;
+    std::vector<hipEvent_t> events; size_t ev_used = 0;
+    std::vector<const char *> ev_names;
     std::map<int, GraphSet> graphs;
     void *comm = nullptr; int rank = 0, world = 1;
     std::map<int, std::pair<void *, int64_t>> bufs;
@@ -83,6 +89,14 @@ struct dqn_handle {
 static Rccl g_rccl;
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// record an event after the launch just enqueued (profiling mode only)
+static void mark(dqn_handle *h, hipStream_t st, const char *name) {
+    if (!h->profiling) return;
+    if (h->ev_used == h->events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->events.push_back(e); }
+    (void)hipEventRecord(h->events[h->ev_used++], st);
+    h->ev_names.push_back(name);
+}
 
 extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(cfg && out, "dqn_create: null argument");
@@ -130,13 +144,15 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->px, Bp * K1 * 4); add(&h->ph1, Bp * H1 * 4); add(&h->ph2, Bp * H2 * 4);
     add(&h->pdz1, Bp * H1 * 4); add(&h->pdz2, Bp * H2 * 4); add(&h->pdz3, Bp * 16 * 4);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
+    add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
+    add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp);
     size_t total = 0;
     for (auto &it : items) total += align_up(it.bytes, 256);
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return fail(DQN_ERR_NOMEM, "hipMalloc(%zu bytes): %s", total, hipGetErrorString(e)); }
     h->arena_bytes = total;
     e = hipMemset(h->arena, 0, total);                   // zero ring (replay_buffer.py:28-32), tree, moments
-    if (e != hipSuccess) { hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "hipMemset: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "hipMemset: %s", hipGetErrorString(e)); }
     size_t off = 0;
     for (auto &it : items) {
         *it.p = (char *)h->arena + off;
@@ -146,26 +162,28 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     DqnState s0{};
     s0.b1pow = 1.0; s0.b2pow = 1.0; s0.pmax = 1.0f; s0.beta = cfg->per_beta; s0.lr = cfg->lr;
     e = hipMemcpy(h->st, &s0, sizeof(s0), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "state init: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "state init: %s", hipGetErrorString(e)); }
     *out = h;
     return DQN_OK;
 }
 
 static void destroy_graphs(dqn_handle *h) {
     for (auto &kv : h->graphs) {
-        if (kv.second.fused) hipGraphExecDestroy(kv.second.fused);
-        if (kv.second.bwd) hipGraphExecDestroy(kv.second.bwd);
-        if (kv.second.apply) hipGraphExecDestroy(kv.second.apply);
+        if (kv.second.fused) (void)hipGraphExecDestroy(kv.second.fused);
+        if (kv.second.bwd) (void)hipGraphExecDestroy(kv.second.bwd);
+        if (kv.second.apply) (void)hipGraphExecDestroy(kv.second.apply);
+        if (kv.second.actor) (void)hipGraphExecDestroy(kv.second.actor);
     }
     h->graphs.clear();
 }
 
 extern "C" int dqn_destroy(dqn_handle *h) {
     if (!h) return DQN_OK;
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     destroy_graphs(h);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-    if (h->arena) hipFree(h->arena);
+    for (auto e : h->events) (void)hipEventDestroy(e);
+    if (h->arena) (void)hipFree(h->arena);
     delete h;
     return DQN_OK;
 }
@@ -250,7 +268,7 @@ extern "C" int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, c
     REQUIRE(n >= 1 && n <= h->cfg.capacity, "dqn_replay_add: n=%d must be in [1, capacity]", n);
     hipStream_t st = (hipStream_t)stream;
     launch_replay_add(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
-                      h->cfg.capacity, h->cfg.obs_dim, s, a, r, s2, d, n);
+                      h->cfg.capacity, h->cfg.obs_dim, s, a, r, s2, d, n, nullptr, 0);
     if (h->cfg.use_per)
         launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, nullptr, nullptr, n, 2,
                          h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
@@ -417,11 +435,13 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st) {
     else
         launch_sample_uniform(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
                               h->cfg.obs_dim, B, h->cfg.seed, 0, 1, nullptr, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx);
+    mark(h, st, h->cfg.use_per ? "per_sample" : "uniform_sample");
     // q_agent.py:159-165 compute_q_targets: three forwards
     FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, true),
                      make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),
                      make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false) };
     launch_qnet_fwd(st, h->m, p, 3, B);
+    mark(h, st, "qnet_fwd_x3");
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
     BwdArgs g{};
     g.q = h->q; g.nq = h->nq; g.nt = h->nt; g.a = h->ba; g.r = h->br; g.d_u8 = h->bd;
@@ -430,21 +450,26 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st) {
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
     launch_bwd_rows(st, h->m, g, B, h->st);
+    mark(h, st, "td_bwd_rows");
     launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
               h->loss_dev, h->st, 1);
+    mark(h, st, "dw");
 }
 
 static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
     enqueue_adam(h, st);                                           // q_learning_functions.py:24-25
-    if (h->cfg.use_per)
+    mark(h, st, "adam");
+    if (h->cfg.use_per) {
         launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
                          h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+        mark(h, st, "per_update");
+    }
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only)
 template <class F>
 static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F body) {
-    if (!st) { body(); HIP_TRY(hipGetLastError()); return DQN_OK; }   // legacy default stream: eager
+    if (!st || h->profiling) { body(); HIP_TRY(hipGetLastError()); return DQN_OK; }   // default stream / profiling: eager
     if (!*slot) {
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -452,7 +477,7 @@ static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F b
         hipError_t e = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess) return fail(DQN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
         e = hipGraphInstantiate(slot, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { *slot = nullptr; return fail(DQN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
     }
     HIP_TRY(hipGraphLaunch(*slot, st));
@@ -489,9 +514,54 @@ extern "C" int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, 
     hipStream_t st = (hipStream_t)stream;
     FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false);
     launch_qnet_fwd(st, h->m, &p, 1, n);
-    launch_policy(st, h->q, n, h->cfg.num_actions, epsilon, seed, ctr, actions);
+    launch_policy(st, h->q, n, h->cfg.num_actions, epsilon, seed, ctr, actions, nullptr);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
+}
+
+// ------------------------------------------------------------------- synthetic actor
+extern "C" int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream) {
+    REQUIRE(h, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&h->st->epsilon, &epsilon, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+extern "C" int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream) {
+    REQUIRE(h && obs, "null argument");
+    REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch, "n_envs=%d exceeds max_batch=%d", n_envs, h->cfg.max_batch);
+    h->p_done = p_done;
+    HIP_TRY(hipMemcpyAsync(h->env_obs, obs, (size_t)n_envs * h->cfg.obs_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DQN_OK;
+}
+
+extern "C" int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream) {
+    REQUIRE(h, "null argument");
+    REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch && n_envs <= h->cfg.capacity,
+            "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    return run_captured(h, &h->graphs[-n_envs].actor, st, [&] {
+        // q_agent.py:176 action = _policy(state)
+        FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, h->q, nullptr, false);
+        launch_qnet_fwd(st, h->m, &p, 1, n_envs);
+        mark(h, st, "act_qnet_fwd");
+        launch_policy(st, h->q, n_envs, h->cfg.num_actions, 0.f, h->cfg.seed, 0, h->env_a, h->st);
+        mark(h, st, "act_policy");
+        // q_agent.py:177 env.step(action): synthetic transition (no physics)
+        launch_synth_env(st, h->st, n_envs, h->cfg.obs_dim, h->cfg.seed, h->p_done, h->env_next, h->env_r, h->env_d);
+        mark(h, st, "synth_env");
+        // q_agent.py:182-183 replay.add(...); state = observation
+        launch_replay_add(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
+                          h->cfg.capacity, h->cfg.obs_dim, h->env_obs, h->env_a, h->env_r, h->env_next, h->env_d,
+                          n_envs, h->env_obs, 1);
+        mark(h, st, "replay_add");
+        if (h->cfg.use_per) {
+            launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, nullptr, nullptr, n_envs, 2,
+                             h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+            mark(h, st, "per_add");
+        }
+    });
 }
 
 extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {
@@ -499,6 +569,30 @@ extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->target, h->params, h->m.P * 4, hipMemcpyDeviceToDevice, st));   // q_agent.py:144
     HIP_TRY(hipMemcpyAsync(h->pack_t, h->pack, h->m.pack_floats * 4, hipMemcpyDeviceToDevice, st));
+    return DQN_OK;
+}
+
+// --------------------------------------------------------------------------- profiling
+extern "C" int dqn_profile_begin(dqn_handle *h, void *stream) {
+    REQUIRE(h, "null argument");
+    h->profiling = true; h->ev_used = 0; h->ev_names.clear();
+    if (h->events.empty()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
+    HIP_TRY(hipEventRecord(h->events[h->ev_used++], (hipStream_t)stream));
+    return DQN_OK;
+}
+
+extern "C" int dqn_profile_end(dqn_handle *h, void *stream, char *names, int32_t name_stride, float *ms,
+                               int32_t max_entries, int32_t *count) {
+    REQUIRE(h && names && ms && count, "null argument");
+    h->profiling = false;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    int n = (int)h->ev_names.size();
+    if (n > max_entries) n = max_entries;
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipEventElapsedTime(&ms[i], h->events[i], h->events[i + 1]));
+        snprintf(names + (size_t)i * name_stride, name_stride, "%s", h->ev_names[i]);
+    }
+    *count = n;
     return DQN_OK;
 }
 

@@ -12,6 +12,7 @@ struct DqnState {
     long long          size;           // ReplayBuffer._num_samples  (replay_buffer.py:34)
     unsigned long long sample_ctr;     // Philox counter of the fused path (one per update)
     unsigned long long epoch;          // write-back epoch for duplicate resolution
+    unsigned long long env_ctr;        // vector env steps taken (Philox counter of policy / synthetic env)
     double             b1pow, b2pow;   // running b1^t, b2^t
     int                adam_count;     // ScaleByAdamState.count
     float              pmax;           // running max priority
@@ -19,6 +20,8 @@ struct DqnState {
     float              lr;
     float              loss;           // last loss
     float              wmax;           // last batch's max raw IS weight
+    float              epsilon;        // exploration rate of the fused actor step
+    float              pad0;
     unsigned int       arrive;         // last-block tickets
     unsigned int       pad;
 };

@@ -56,13 +56,16 @@ void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
-                   unsigned long long ctr, int32_t *actions);
+                   unsigned long long ctr, int32_t *actions, const DqnState *st_from);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
 
 // ----- replay / PER ---------------------------------------------------------------------
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
                        float *observations, uint8_t *dones, long long N, int D, const float *s,
-                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n);
+                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n,
+                       float *s_advance, int bump_env);
+void launch_synth_env(hipStream_t st_, const DqnState *st, int n, int D, unsigned long long seed, float p_done,
+                      float *obs_next, float *r, uint8_t *d);
 void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,
                            const float *rewards, const float *observations, const uint8_t *dones, int D,
                            int B, unsigned long long seed, unsigned long long ctr, int from_state,

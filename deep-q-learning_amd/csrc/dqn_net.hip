@@ -597,9 +597,10 @@ void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, c
 // compute_action (q_learning_functions.py:70): argmax, first max wins.
 __global__ void __launch_bounds__(256)
 k_policy(const float *__restrict__ q, int n, int A, float epsilon, unsigned long long seed,
-         unsigned long long ctr, int32_t *actions) {
+         unsigned long long ctr, int32_t *actions, const DqnState *st_from) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (st_from) { epsilon = st_from->epsilon; ctr = st_from->env_ctr; }
     const u32x4 o = philox_draw(seed, ctr, (uint32_t)i, DQN_STREAM_POLICY);
     int act;
     if (epsilon < u01(o.x)) {
@@ -612,8 +613,8 @@ k_policy(const float *__restrict__ q, int n, int A, float epsilon, unsigned long
 }
 
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
-                   unsigned long long ctr, int32_t *actions) {
-    hipLaunchKernelGGL(k_policy, dim3((n + 255) / 256), dim3(256), 0, s, q, n, A, epsilon, seed, ctr, actions);
+                   unsigned long long ctr, int32_t *actions, const DqnState *st_from) {
+    hipLaunchKernelGGL(k_policy, dim3((n + 255) / 256), dim3(256), 0, s, q, n, A, epsilon, seed, ctr, actions, st_from);
 }
 
 __global__ void __launch_bounds__(256) k_u8_to_f32(const uint8_t *__restrict__ in, float *out, int n) {

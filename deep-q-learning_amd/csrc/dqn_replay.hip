@@ -15,16 +15,19 @@
 // reads the same ring_counter; the last block to finish commits counter and size.
 __global__ void __launch_bounds__(256)
 k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, float *observations,
-             uint8_t *dones, long long N, int D, const float *__restrict__ s,
+             uint8_t *dones, long long N, int D, const float *s,
              const int32_t *__restrict__ a, const float *__restrict__ r,
-             const float *__restrict__ s2, const uint8_t *__restrict__ d, int n) {
+             const float *s2, const uint8_t *__restrict__ d, int n, float *s_advance,
+             int bump_env) {
     const unsigned long long c0 = st->ring_counter;
     const int total = n * D;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int j = t / D, e = t - j * D;
         const long long k = (long long)((c0 + (unsigned long long)j) % (unsigned long long)N);
-        states[k * D + e] = s[t];                                       // :59
-        observations[k * D + e] = s2[t];                                // :62
+        const float sv = s[t], ov = s2[t];
+        states[k * D + e] = sv;                                         // :59
+        observations[k * D + e] = ov;                                   // :62
+        if (s_advance) s_advance[t] = ov;                               // q_agent.py:183 state = observation
         if (e == 0) {
             actions[k] = a[j];                                          // :60
             rewards[k] = r[j];                                          // :61
@@ -39,10 +42,36 @@ k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, floa
             const unsigned long long c1 = c0 + (unsigned long long)n;
             st->ring_counter = c1;                                                     // :64
             st->size = (long long)(c1 < (unsigned long long)N ? c1 : (unsigned long long)N);  // :65
+            if (bump_env) st->env_ctr += 1ull;
             st->arrive = 0;
             __threadfence();
         }
     }
+}
+
+// ---------------------------------------------------------------- synthetic env
+// no physics. Per env i and vector step c: obs' ~ N(0,1)^D, r ~ N(0,1)
+// (+-100 on terminals), d ~ Bernoulli(p_done), all from Philox stream 3 and exactly
+// reproducible on the CPU: a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3).
+__device__ __forceinline__ float ih_normal(const u32x4 o) {
+    return (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;
+}
+
+__global__ void __launch_bounds__(256)
+k_synth_env(const DqnState *st, int n, int D, unsigned long long seed, float p_done,
+            float *obs_next, float *r, uint8_t *d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c = st->env_ctr;
+    const uint32_t base = (uint32_t)i * (uint32_t)(D + 1);
+    for (int e = 0; e < D; ++e)
+        obs_next[(long long)i * D + e] = ih_normal(philox_draw(seed, c, base + (uint32_t)e, DQN_STREAM_ENV));
+    const u32x4 o = philox_draw(seed, c, base + (uint32_t)D, DQN_STREAM_ENV);
+    const bool done = u01(o.x) < p_done;
+    float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
+    if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
+    r[i] = rew;
+    d[i] = done ? 1 : 0;
 }
 
 // ------------------------------------------------------------- uniform sampling
@@ -206,13 +235,19 @@ k_per_write(DqnState *st, float *tree, unsigned long long *stamp, long long N, i
 // --------------------------------------------------------------------- launchers
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
                        float *observations, uint8_t *dones, long long N, int D, const float *s,
-                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n) {
+                       const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n,
+                       float *s_advance, int bump_env) {
     const int total = n * D;
     int blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_replay_add, dim3(blocks), dim3(256), 0, st_, st, states, actions, rewards,
-                       observations, dones, N, D, s, a, r, s2, d, n);
+                       observations, dones, N, D, s, a, r, s2, d, n, s_advance, bump_env);
+}
+
+void launch_synth_env(hipStream_t st_, const DqnState *st, int n, int D, unsigned long long seed, float p_done,
+                      float *obs_next, float *r, uint8_t *d) {
+    hipLaunchKernelGGL(k_synth_env, dim3((n + 255) / 256), dim3(256), 0, st_, st, n, D, seed, p_done, obs_next, r, d);
 }
 
 void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,

@@ -281,5 +281,30 @@ class Engine:
     def update_apply(self, B, stream=None):
         L.check(self.lib.dqn_update_apply(self.h, B, self._s(stream)))
 
+    # ------------------------------------------------------------ synthetic actor
+    def set_epsilon(self, epsilon):
+        L.check(self.lib.dqn_set_epsilon(self.h, float(epsilon), self._s()))
+
+    def env_reset(self, obs, p_done=0.01):
+        obs = self.dev(obs, torch.float32).view(-1, self.cfg.obs_dim)
+        L.check(self.lib.dqn_env_reset(self.h, _ptr(obs), obs.shape[0], float(p_done), self._s()))
+        self.n_envs = obs.shape[0]
+
+    def actor_step(self, stream=None):
+        """one vector env step (q_agent.py:176-183) on the device-resident synthetic envs"""
+        L.check(self.lib.dqn_actor_step(self.h, self.n_envs, self._s(stream)))
+
+    # ------------------------------------------------------------------ profiling
+    def profile_begin(self, stream=None):
+        L.check(self.lib.dqn_profile_begin(self.h, self._s(stream)))
+
+    def profile_end(self, stream=None, max_entries=256):
+        """-> [(kernel name, elapsed ms)] for every launch since profile_begin (HIP events)"""
+        names = C.create_string_buffer(32 * max_entries)
+        ms = (C.c_float * max_entries)()
+        n = C.c_int32()
+        L.check(self.lib.dqn_profile_end(self.h, self._s(stream), names, 32, ms, max_entries, C.byref(n)))
+        return [(names.raw[32 * i:32 * i + 32].split(b"\0", 1)[0].decode(), ms[i]) for i in range(n.value)]
+
     def last_loss(self):
         return self.buffer(L.BUF_LOSS)[:1]

@@ -42,7 +42,8 @@ typedef enum {                                                              /* d
     DQN_BUF_PARAMS = 0, DQN_BUF_TARGET = 1, DQN_BUF_MU = 2, DQN_BUF_NU = 3, DQN_BUF_GRAD = 4,
     DQN_BUF_TREE = 5, DQN_BUF_STATES = 6, DQN_BUF_ACTIONS = 7, DQN_BUF_REWARDS = 8,
     DQN_BUF_OBSERVATIONS = 9, DQN_BUF_DONES = 10,
-    DQN_BUF_BATCH_IDX = 11, DQN_BUF_BATCH_ISW = 12, DQN_BUF_BATCH_TD = 13, DQN_BUF_LOSS = 14
+    DQN_BUF_BATCH_IDX = 11, DQN_BUF_BATCH_ISW = 12, DQN_BUF_BATCH_TD = 13, DQN_BUF_LOSS = 14,
+    DQN_BUF_ENV_OBS = 15, DQN_BUF_ENV_ACTIONS = 16
 } dqn_buffer_id;
 
 typedef struct dqn_handle dqn_handle;
@@ -152,8 +153,25 @@ int dqn_update_apply(dqn_handle *h, int32_t B, void *stream);      /* optimizer 
 int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, uint64_t seed,
             uint64_t ctr, int32_t *actions, void *stream);
 
+/* One vector step of the env loop (q_agent.py:176-183) on n_envs synthetic environments that
+ * live on the device: action = _policy(state) -> synthetic transition (obs' ~
+ * N(0,1), r ~ N(0,1) or +-100 on terminals, done ~ Bernoulli(p_done); Philox stream 3) ->
+ * replay.add -> state = observation. Graph-replayed; epsilon and the step counter live on
+ * the device. dqn_env_reset uploads the initial observations [n_envs, D]. */
+int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream);
+int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream);
+int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
+
 /* Agent._update_target_model (q_agent.py:143-144) */
 int dqn_sync_target(dqn_handle *h, void *stream);
+
+/* per-kernel timing with HIP events on `stream` (bench.py's live roofline measurement): between
+ * begin and end every library launch is run eagerly and bracketed by events; end synchronises and
+ * returns up to max_entries (name, elapsed ms) pairs, names as NUL-terminated strings of
+ * name_stride bytes each. */
+int dqn_profile_begin(dqn_handle *h, void *stream);
+int dqn_profile_end(dqn_handle *h, void *stream, char *names_host, int32_t name_stride, float *ms_host,
+                    int32_t max_entries, int32_t *count_host);
 
 /* gradient all-reduce for independent per-GPU learners (no counterpart in the
  * reference). unique_id: the 128-byte ncclUniqueId from rank 0. */

@@ -108,6 +108,11 @@ void  orc_act(orc_dims m, const float *P, const float *s, int32_t n, float epsil
 void  orc_obs_augment(const float *obs, const int32_t *step, int32_t max_steps,
                       int32_t n, int32_t D, float *out);
 
+/* synthetic vector env (build spec): obs' ~ N(0,1)^D as Irwin-Hall(4) sums,
+ * r ~ N(0,1) (+-100 on terminals), d ~ Bernoulli(p_done); Philox stream 3, counter = env step */
+void  orc_synth_env(int32_t n, int32_t D, uint64_t seed, uint64_t env_ctr, float p_done,
+                    float *obs_next, float *r, uint8_t *d);
+
 /* one whole update on the CPU (bench.py cpu_baseline "port"): PER sample -> gather ->
  * q_targets -> grads -> adam -> PER write-back. Returns loss. */
 typedef struct {
@@ -122,6 +127,9 @@ int   orc_learner_init(orc_learner *l, orc_dims m, orc_opt opt, float gamma, int
                        orc_replay *rb, orc_per *per, const float *P0, uint64_t seed);
 void  orc_learner_free(orc_learner *l);
 float orc_learner_update(orc_learner *l, int32_t B);
+/* q_agent.py:176-183 for n envs: act (epsilon-greedy) -> synthetic transition -> replay.add (+PER leaf) ->
+ * state = observation. obs is [n,D] and is advanced in place; *env_ctr is incremented. */
+void  orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon, float p_done, uint64_t *env_ctr);
 
 #ifdef __cplusplus
 }

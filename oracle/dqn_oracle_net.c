@@ -291,3 +291,43 @@ float orc_learner_update(orc_learner *l, int32_t B) {
     }
     return loss;
 }
+
+/* ------------------------------------------------------------ synthetic actor */
+static inline float ih_normal(const uint32_t o[4]) {
+    return (((orc_u01(o[0]) + orc_u01(o[1])) + (orc_u01(o[2]) + orc_u01(o[3]))) - 2.0f) * 1.73205078f;
+}
+
+void orc_synth_env(int32_t n, int32_t D, uint64_t seed, uint64_t env_ctr, float p_done,
+                   float *obs_next, float *r, uint8_t *d) {
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    for (int32_t i = 0; i < n; ++i) {
+        const uint32_t base = (uint32_t)i * (uint32_t)(D + 1);
+        uint32_t c[4] = { (uint32_t)env_ctr, (uint32_t)(env_ctr >> 32), 0, ORC_STREAM_ENV }, o[4];
+        for (int32_t e = 0; e < D; ++e) {
+            c[2] = base + (uint32_t)e;
+            orc_philox4x32_10(c, key, o);
+            obs_next[(int64_t)i * D + e] = ih_normal(o);
+        }
+        c[2] = base + (uint32_t)D;
+        orc_philox4x32_10(c, key, o);
+        const int done = orc_u01(o[0]) < p_done;
+        float rew = (((orc_u01(o[1]) + orc_u01(o[2])) + (orc_u01(o[3]) + orc_u01(o[0]))) - 2.0f) * 1.73205078f;
+        if (done) rew = (o[1] & 1u) ? 100.0f : -100.0f;
+        r[i] = rew;
+        d[i] = done ? 1 : 0;
+    }
+}
+
+void orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon, float p_done, uint64_t *env_ctr) {
+    const int32_t D = l->m.D;
+    int32_t *a = (int32_t *)malloc(sizeof(int32_t) * n), *slots = (int32_t *)malloc(sizeof(int32_t) * n);
+    float *next = (float *)malloc(sizeof(float) * (size_t)n * D), *r = (float *)malloc(sizeof(float) * n);
+    uint8_t *d = (uint8_t *)malloc(n);
+    orc_act(l->m, l->P, obs, n, epsilon, l->seed, *env_ctr, a);                 /* q_agent.py:176 */
+    orc_synth_env(n, D, l->seed, *env_ctr, p_done, next, r, d);                  /* :177 (synthetic) */
+    orc_replay_add(l->rb, obs, a, r, next, d, n, slots);                         /* :182 */
+    if (l->per) orc_per_add(l->per, slots, n);
+    memcpy(obs, next, sizeof(float) * (size_t)n * D);                            /* :183 */
+    *env_ctr += 1;
+    free(a); free(slots); free(next); free(r); free(d);
+}

@@ -351,3 +351,29 @@ def obs_augment(obs, step, max_steps):
     obs = np.asarray(obs, np.float32)
     frac = (np.asarray(step, np.float64) / max_steps)
     return np.concatenate([obs, frac[:, None]], axis=1).astype(np.float32)
+
+
+def synth_env(n, D, seed, env_ctr, p_done):
+    """Synthetic vector env (build spec); Philox stream 3, counter = env step.
+    Returns (obs_next [n,D], r [n], d [n] u8)."""
+    k = (np.arange(n, dtype=np.uint32)[:, None] * np.uint32(D + 1) + np.arange(D + 1, dtype=np.uint32)[None, :]).ravel()
+    c = np.zeros((k.size, 4), np.uint32)
+    c[:, 0] = env_ctr & 0xFFFFFFFF
+    c[:, 1] = (env_ctr >> 32) & 0xFFFFFFFF
+    c[:, 2] = k
+    c[:, 3] = STREAM_ENV
+    key = np.zeros((k.size, 2), np.uint32)
+    key[:, 0] = seed & 0xFFFFFFFF
+    key[:, 1] = (seed >> 32) & 0xFFFFFFFF
+    o = philox4x32_10(c, key).reshape(n, D + 1, 4)
+    u = u01(o)
+    f = np.float32
+    nrm = ((((u[..., 0] + u[..., 1]).astype(f) + (u[..., 2] + u[..., 3]).astype(f)).astype(f) - f(2.0)).astype(f)
+           * f(1.73205078)).astype(f)
+    obs_next = nrm[:, :D]
+    last = u[:, D, :]
+    done = last[:, 0] < f(p_done)
+    rew = ((((last[:, 1] + last[:, 2]).astype(f) + (last[:, 3] + last[:, 0]).astype(f)).astype(f) - f(2.0)).astype(f)
+           * f(1.73205078)).astype(f)
+    rew = np.where(done, np.where(o[:, D, 1] & np.uint32(1), f(100.0), f(-100.0)), rew).astype(f)
+    return obs_next.astype(f), rew, done.astype(np.uint8)

@@ -224,3 +224,17 @@ class CLearner:
 
     def sync_target(self):
         C.memmove(self.l.Pt, self.l.P, self.n * 4)
+
+    def actor_step(self, obs, epsilon, p_done, env_ctr):
+        """advances obs in place; returns the new env counter"""
+        c = C.c_uint64(env_ctr)
+        lib().orc_learner_actor_step(C.byref(self.l), _p(obs), C.c_int32(obs.shape[0]), C.c_float(epsilon),
+                                     C.c_float(p_done), C.byref(c))
+        return c.value
+
+
+def synth_env(n, D, seed, env_ctr, p_done):
+    obs = np.empty((n, D), np.float32); r = np.empty(n, np.float32); d = np.empty(n, np.uint8)
+    lib().orc_synth_env(C.c_int32(n), C.c_int32(D), C.c_uint64(seed), C.c_uint64(env_ctr), C.c_float(p_done),
+                        _p(obs), _p(r), _p(d))
+    return obs, r, d

@@ -305,3 +305,63 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
         # priorities come from |delta| (FP, 1e-5-level differences) -> tree close, not bitwise
         assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
     e.close()
+
+
+# ----------------------------------------------------------------- synthetic actor
+@pytest.mark.parametrize("per", [False, True])
+def test_actor_step_bitexact(dq, per):
+    """q_agent.py:176-183 on device-resident synthetic envs: after several graph-replayed vector steps
+    (with ring wrap) the ring, the tree, the observations and the taken actions equal the oracle's."""
+    import torch
+    dims = CFGS["cfg2"]
+    D = dims[0]
+    L_, n = 11, 256
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=n, seed=31)
+    cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
+    P0 = rand_params(dims, 80)
+    e.set_params(P0)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, n, cr, ct, P0, 31)
+    obs = np.random.default_rng(81).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.3)
+    ctr = 0
+    with torch.cuda.stream(e.stream):
+        for it in range(11):                                   # 11 * 256 > 2048: wraps
+            ctr = lrn.actor_step(obs, 0.3, 0.05, ctr)
+            e.actor_step()
+        e.stream.synchronize()
+    L = dq._lib
+    assert e.replay_size() == (cr.size, cr.rb.counter)
+    got = (e.buffer(L.BUF_STATES).view(N, D), e.buffer(L.BUF_ACTIONS, torch.int32), e.buffer(L.BUF_REWARDS),
+           e.buffer(L.BUF_OBSERVATIONS).view(N, D), e.buffer(L.BUF_DONES, torch.uint8))
+    for x, y in zip(got, cr.arrays()):
+        assert np.array_equal(host(x), y)
+    assert np.array_equal(host(e.buffer(L.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
+    if per:
+        assert np.array_equal(host(e.buffer(L.BUF_TREE)), ct.tree)
+    e.close()
+
+
+def test_profile_hooks_and_error_paths(dq):
+    """dqn_profile_* returns one entry per launch; bad arguments come back as errors, not crashes"""
+    import torch
+    dims = CFGS["cfg1"]
+    e = mk(dq, dims, capacity=1024, use_per=True, max_batch=64)
+    rng = np.random.default_rng(0)
+    e.replay_add(rng.standard_normal((512, 9)), rng.integers(0, 4, 512), rng.standard_normal(512),
+                 rng.standard_normal((512, 9)), rng.random(512) < 0.1)
+    e.set_params(rand_params(dims, 1)); e.sync_target()
+    with torch.cuda.stream(e.stream):
+        e.profile_begin()
+        e.update_backward(64); e.update_apply(64)
+        prof = e.profile_end()
+    assert [k for k, _ in prof] == ["per_sample", "qnet_fwd_x3", "td_bwd_rows", "dw", "adam", "per_update"]
+    assert all(ms >= 0 for _, ms in prof)
+    with pytest.raises(dq._lib.DqnError):
+        e.update(65)                                           # > max_batch
+    u = mk(dq, dims, capacity=64, use_per=False, max_batch=8)
+    with pytest.raises(dq._lib.DqnError):
+        u.per_update(np.zeros(4, np.int32), np.ones(4, np.float32))   # PER call on a uniform handle
+    with pytest.raises(dq._lib.DqnError):
+        mk(dq, (9, 30, 64, 4))                                 # hidden1 not a multiple of 16
+    e.close(); u.close()
