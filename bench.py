@@ -32,6 +32,7 @@ LOG2N = 20
 B = 1024
 N_ENVS = 256
 TRAIN_FREQ = 4            # Test/lunar_lander.py:30
+ITERS_PER_GRAPH = 10      # inner-loop iterations captured per hipGraph launch (single GPU)
 P_DONE = 0.01
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -49,19 +50,15 @@ def algorithmic_cost(name, L, n_params):
         return "hbm", (8 * L + 4) * N_ENVS
     if name == "adam":
         return "hbm", 28 * n_params
-    if name == "replay_add":
-        return "hbm", 2 * (8 * D + 9) * N_ENVS
-    if name == "synth_env":
-        return "hbm", (4 * D + 5) * N_ENVS
-    if name == "act_policy":
-        return "hbm", (4 * A + 4) * N_ENVS
+    if name == "env_step_add":        # synthetic transition + ring insert + PER leaf-range insert
+        return "hbm", ((4 * D + 5) + 2 * (8 * D + 9) + (8 * L + 4)) * N_ENVS
     if name == "qnet_fwd_x3":
         return "mfma", 3 * F * B
-    if name == "act_qnet_fwd":
+    if name == "act_fwd_policy":
         return "mfma", F * N_ENVS
     if name == "td_bwd_rows":
         return "mfma", (2 * (1 + A) * H2 + 2 * H1 * H2) * B
-    if name == "dw":
+    if name in ("dw", "dw_adam"):
         return "mfma", 2 * B * (D * H1 + H1 * H2 + H2 * (1 + A))
     return "hbm", 0
 
@@ -169,15 +166,20 @@ def main():
     grad = eng.buffer(L.BUF_GRAD) if world > 1 else None
     st = eng.stream
 
-    def step():
-        for _ in range(TRAIN_FREQ):
-            eng.actor_step(st)
+    def run_steps(k):
+        """exactly k steps; a step = TRAIN_FREQ vector env steps + one update"""
         if world > 1:
-            eng.update_backward(B, st)
-            dist.all_reduce(grad)                            # RCCL, sum; /world is inside the optimizer
-            eng.update_apply(B, st)
+            for _ in range(k):
+                for _ in range(TRAIN_FREQ):
+                    eng.actor_step(st)
+                eng.update_backward(B, st)
+                dist.all_reduce(grad)                        # RCCL, sum; /world is inside the optimizer
+                eng.update_apply(B, st)
         else:
-            eng.update(B, st)
+            for _ in range(k // ITERS_PER_GRAPH):
+                eng.train_iters(ITERS_PER_GRAPH, TRAIN_FREQ, B, st)
+            if k % ITERS_PER_GRAPH:
+                eng.train_iters(k % ITERS_PER_GRAPH, TRAIN_FREQ, B, st)
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,12 +188,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.cuda.stream(st):
-        for _ in range(args.warmup):
-            step()
+        run_steps(args.warmup)
+        run_steps(args.steps)                                # also instantiates every graph shape used below
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run_steps(args.steps)
         barrier()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], device=eng.device, dtype=torch.float64)
@@ -200,13 +201,18 @@ def main():
         dt = float(t.item())
 
         # update-only and actor-only rates (same run, extra information)
-        barrier(); t0 = time.perf_counter()
-        for _ in range(args.steps):
+        def upd_only(k):
             if world > 1:
-                eng.update_backward(B, st); dist.all_reduce(grad); eng.update_apply(B, st)
+                for _ in range(k):
+                    eng.update_backward(B, st); dist.all_reduce(grad); eng.update_apply(B, st)
             else:
-                eng.update(B, st)
+                for _ in range(k // ITERS_PER_GRAPH):
+                    eng.train_iters(ITERS_PER_GRAPH, 0, B, st)
+        upd_only(ITERS_PER_GRAPH)
+        barrier(); t0 = time.perf_counter()
+        upd_only(args.steps)
         barrier(); dt_upd = time.perf_counter() - t0
+        n_upd = args.steps if world > 1 else args.steps // ITERS_PER_GRAPH * ITERS_PER_GRAPH
         t0 = time.perf_counter()
         for _ in range(args.steps):
             eng.actor_step(st)
@@ -217,8 +223,7 @@ def main():
         if rank == 0:
             for _ in range(args.profile_steps):
                 eng.profile_begin(st)
-                eng.actor_step(st)
-                eng.update_backward(B, st); eng.update_apply(B, st)
+                eng.train_iters(1, TRAIN_FREQ, B, st)        # profiling mode: eager, one launch per event pair
                 for name, ms in eng.profile_end(st):
                     kern.setdefault(name, []).append(ms)
     loss = float(eng.last_loss().item())
@@ -227,7 +232,7 @@ def main():
     if rank == 0:
         per_step = {}
         for name, v in kern.items():
-            launches = TRAIN_FREQ if name in ("act_qnet_fwd", "act_policy", "synth_env", "replay_add", "per_add") else 1
+            launches = TRAIN_FREQ if name in ("act_fwd_policy", "env_step_add") else 1
             bound, units = algorithmic_cost(name, LOG2N, eng.param_count)
             avg_ms = float(np.median(v))
             ach = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12) if avg_ms > 0 else 0.0
@@ -238,6 +243,7 @@ def main():
         dom = max(per_step, key=lambda k: per_step[k]["avg_us"] * per_step[k]["launches_per_step"])
         roof = {k: per_step[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
         roof.update({"kernel": dom, "avg_us": per_step[dom]["avg_us"], "traffic": None,
+                     "launches_per_step": per_step[dom]["launches_per_step"],
                      "timing": "HIP events around each eager launch on the launch stream, median of "
                                f"{args.profile_steps} (event overhead included); rocprofv3 summary in profiles/"})
         out = {
@@ -250,7 +256,7 @@ def main():
                        "n_envs_per_gpu": N_ENVS, "replay_capacity": 1 << LOG2N, "per": True, "optimizer": "adamw",
                        "train_frequency": TRAIN_FREQ, "parallelism": f"dp{world} independent learners + grad all-reduce"},
             "env_steps_per_sec": world * args.steps * N_ENVS * TRAIN_FREQ / dt,
-            "update_only_per_sec": world * args.steps / dt_upd,
+            "update_only_per_sec": world * n_upd / dt_upd,
             "actor_only_env_steps_per_sec": world * args.steps * N_ENVS / dt_act,
             "final_loss": loss,
             "roofline": roof,

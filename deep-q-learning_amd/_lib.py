@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdqn_hip.so")
+LIB_PATH = os.environ.get("DQN_HIP_LIB", os.path.join(_HERE, "libdqn_hip.so"))   # override: diagnostic builds only
 
 # dqn_status / enums (include/dqn_hip.h)
 OPT_ADAM, OPT_ADAMW = 0, 1
@@ -46,6 +46,7 @@ SIGNATURES = {
     "dqn_per_sample": [_P, _I32, _F, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P],
     "dqn_per_update": [_P, _P, _P, _I32, _P],
     "dqn_per_set": [_P, _P, _P, _I32, _P],
+    "dqn_per_update_sorted": [_P, _P, _P, _I32, _P],
     "dqn_qnet_forward": [_P, C.c_int, _P, _I32, _P, _P, _P],
     "dqn_td_targets": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P],
     "dqn_q_targets": [_P, _P, _P, _P, _P, _P, _I32, _P, _P],
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dqn_set_epsilon": [_P, _F, _P],
     "dqn_env_reset": [_P, _P, _I32, _F, _P],
     "dqn_actor_step": [_P, _I32, _P],
+    "dqn_train_iters": [_P, _I32, _I32, _I32, _I32, _P],
     "dqn_profile_begin": [_P, _P],
     "dqn_profile_end": [_P, _P, _P, _I32, _P, _I32, C.POINTER(_I32)],
     "dqn_comm_unique_id": [_P],

@@ -82,6 +82,8 @@ struct dqn_handle {
     std::vector<hipEvent_t> events; size_t ev_used = 0;
     std::vector<const char *> ev_names;
     std::map<int, GraphSet> graphs;
+    std::map<std::vector<int>, hipGraphExec_t> loop_graphs;      // (iters, env_steps, n_envs, B) -> graph
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // parallel graph branch
     void *comm = nullptr; int rank = 0, world = 1;
     std::map<int, std::pair<void *, int64_t>> bufs;
 };
@@ -163,6 +165,11 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     s0.b1pow = 1.0; s0.b2pow = 1.0; s0.pmax = 1.0f; s0.beta = cfg->per_beta; s0.lr = cfg->lr;
     e = hipMemcpy(h->st, &s0, sizeof(s0), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "state init: %s", hipGetErrorString(e)); }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "stream/event creation failed");
+    }
     *out = h;
     return DQN_OK;
 }
@@ -175,6 +182,8 @@ static void destroy_graphs(dqn_handle *h) {
         if (kv.second.actor) (void)hipGraphExecDestroy(kv.second.actor);
     }
     h->graphs.clear();
+    for (auto &kv : h->loop_graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->loop_graphs.clear();
 }
 
 extern "C" int dqn_destroy(dqn_handle *h) {
@@ -183,6 +192,9 @@ extern "C" int dqn_destroy(dqn_handle *h) {
     destroy_graphs(h);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->events) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->arena) (void)hipFree(h->arena);
     delete h;
     return DQN_OK;
@@ -269,9 +281,7 @@ extern "C" int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, c
     hipStream_t st = (hipStream_t)stream;
     launch_replay_add(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
                       h->cfg.capacity, h->cfg.obs_dim, s, a, r, s2, d, n, nullptr, 0);
-    if (h->cfg.use_per)
-        launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, nullptr, nullptr, n, 2,
-                         h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
+    if (h->cfg.use_per) launch_per_add(st, h->st, h->tree, h->Ntree, h->L, n, h->cfg.capacity);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -325,6 +335,15 @@ extern "C" int dqn_per_update(dqn_handle *h, const int32_t *idx, const float *td
 }
 extern "C" int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream) {
     return per_write(h, idx, prio, B, 0, stream);
+}
+extern "C" int dqn_per_update_sorted(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream) {
+    REQUIRE(h && idx && td_abs, "null argument");
+    if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
+    REQUIRE(B >= 1, "B must be >= 1");
+    launch_per_write_sorted((hipStream_t)stream, h->st, h->tree, h->Ntree, h->L, idx, td_abs, B, 1,
+                            h->cfg.per_alpha, h->cfg.per_eps);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
 }
 
 // ------------------------------------------------------------------------------ network
@@ -401,7 +420,7 @@ extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, co
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3; g.loss_part = h->loss_part;
     launch_bwd_rows(st, h->m, g, B, h->st);
     launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
-              loss ? loss : h->loss_dev, h->st, 0);
+              loss ? loss : h->loss_dev, h->st, 0, AdamArgs{});
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -426,7 +445,22 @@ extern "C" int dqn_train_step(dqn_handle *h, const float *s, const float *target
 }
 
 // ------------------------------------------------------------------------ fused update
-static void enqueue_backward(dqn_handle *h, int B, hipStream_t st) {
+static AdamArgs adam_args(dqn_handle *h) {
+    return AdamArgs{h->params, h->mu, h->nu, h->pack, h->cfg.optimizer == DQN_OPT_ADAMW, h->cfg.b1, h->cfg.b2,
+                    h->cfg.eps, h->cfg.weight_decay, 1.0f / (float)h->world};
+}
+
+static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
+    // the batch indices come from dqn_per_sample's stratified descent: non-decreasing
+    launch_per_write_sorted(st, h->st, h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
+                            h->cfg.per_alpha, h->cfg.per_eps);
+    mark(h, st, "per_update");
+}
+
+// sample -> three forwards -> TD / row backward -> weight gradients.
+// fuse_adam: optimizer applied in the dW epilogue (single GPU). fork: run the PER write-back on a
+// parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
+static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fork = false) {
     // q_agent.py:147-153 sample_batch
     if (h->cfg.use_per)
         launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
@@ -451,19 +485,46 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st) {
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
     launch_bwd_rows(st, h->m, g, B, h->st);
     mark(h, st, "td_bwd_rows");
+    if (fork && h->cfg.use_per) {
+        (void)hipEventRecord(h->ev_fork, st);
+        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        enqueue_per_writeback(h, B, h->side);
+        (void)hipEventRecord(h->ev_join, h->side);
+    }
     launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
-              h->loss_dev, h->st, 1);
-    mark(h, st, "dw");
+              h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{});
+    mark(h, st, fuse_adam ? "dw_adam" : "dw");
+    if (fork && h->cfg.use_per) (void)hipStreamWaitEvent(st, h->ev_join, 0);
 }
 
 static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
     enqueue_adam(h, st);                                           // q_learning_functions.py:24-25
     mark(h, st, "adam");
-    if (h->cfg.use_per) {
-        launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
-                         h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
-        mark(h, st, "per_update");
+    if (h->cfg.use_per) enqueue_per_writeback(h, B, st);
+}
+
+// the whole Agent._step; single GPU: optimizer fused into dW, PER write-back on a parallel branch
+static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing) {
+    if (h->world == 1) {
+        const bool fork = capturing && !h->profiling;
+        enqueue_backward(h, B, st, true, fork);
+        if (!fork && h->cfg.use_per) enqueue_per_writeback(h, B, st);
+    } else {
+        enqueue_backward(h, B, st);
+        enqueue_apply(h, B, st);
     }
+}
+
+// q_agent.py:176-183 for n_envs device-resident synthetic envs: two kernels
+static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st) {
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);       // :176 _policy(state)
+    p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
+    launch_qnet_fwd(st, h->m, &p, 1, n_envs);
+    mark(h, st, "act_fwd_policy");
+    launch_env_step(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones, h->cfg.capacity,
+                    h->cfg.obs_dim, h->cfg.use_per ? h->tree : nullptr, h->Ntree, h->L, h->env_obs, h->env_a,
+                    n_envs, h->cfg.seed, h->p_done);                                        // :177-183
+    mark(h, st, "env_step_add");
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only)
@@ -494,7 +555,7 @@ static int check_B(dqn_handle *h, int32_t B) {
 extern "C" int dqn_update_fused(dqn_handle *h, int32_t B, void *stream) {
     int rc = check_B(h, B); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return run_captured(h, &h->graphs[B].fused, st, [&] { enqueue_backward(h, B, st); enqueue_apply(h, B, st); });
+    return run_captured(h, &h->graphs[B].fused, st, [&] { enqueue_update(h, B, st, st && !h->profiling); });
 }
 extern "C" int dqn_update_backward(dqn_handle *h, int32_t B, void *stream) {
     int rc = check_B(h, B); if (rc) return rc;
@@ -512,9 +573,9 @@ extern "C" int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, 
     REQUIRE(h && s && actions, "null argument");
     REQUIRE(n >= 1 && n <= h->cfg.max_batch, "n=%d exceeds max_batch=%d", n, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
-    FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false);
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, s, nullptr, nullptr, false);
+    p.act_out = actions; p.act_state = nullptr; p.act_eps = epsilon; p.act_seed = seed; p.act_ctr = ctr;
     launch_qnet_fwd(st, h->m, &p, 1, n);
-    launch_policy(st, h->q, n, h->cfg.num_actions, epsilon, seed, ctr, actions, nullptr);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -541,25 +602,24 @@ extern "C" int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream) {
     REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch && n_envs <= h->cfg.capacity,
             "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
-    return run_captured(h, &h->graphs[-n_envs].actor, st, [&] {
-        // q_agent.py:176 action = _policy(state)
-        FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, h->q, nullptr, false);
-        launch_qnet_fwd(st, h->m, &p, 1, n_envs);
-        mark(h, st, "act_qnet_fwd");
-        launch_policy(st, h->q, n_envs, h->cfg.num_actions, 0.f, h->cfg.seed, 0, h->env_a, h->st);
-        mark(h, st, "act_policy");
-        // q_agent.py:177 env.step(action): synthetic transition (no physics)
-        launch_synth_env(st, h->st, n_envs, h->cfg.obs_dim, h->cfg.seed, h->p_done, h->env_next, h->env_r, h->env_d);
-        mark(h, st, "synth_env");
-        // q_agent.py:182-183 replay.add(...); state = observation
-        launch_replay_add(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
-                          h->cfg.capacity, h->cfg.obs_dim, h->env_obs, h->env_a, h->env_r, h->env_next, h->env_d,
-                          n_envs, h->env_obs, 1);
-        mark(h, st, "replay_add");
-        if (h->cfg.use_per) {
-            launch_per_write(st, h->st, h->tree, h->stamp, h->Ntree, h->L, nullptr, nullptr, n_envs, 2,
-                             h->cfg.per_alpha, h->cfg.per_eps, h->cfg.capacity);
-            mark(h, st, "per_add");
+    return run_captured(h, &h->graphs[-n_envs].actor, st, [&] { enqueue_actor(h, n_envs, st); });
+}
+
+/* n_iters x (env_steps vector env steps + one update) as ONE graph launch */
+extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps, int32_t n_envs, int32_t B,
+                               void *stream) {
+    int rc = check_B(h, B); if (rc) return rc;
+    REQUIRE(n_iters >= 1 && n_iters <= 256 && env_steps >= 0 && env_steps <= 64, "n_iters / env_steps out of range");
+    REQUIRE(env_steps == 0 || (n_envs >= 1 && n_envs <= h->cfg.max_batch && n_envs <= h->cfg.capacity),
+            "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
+    if (h->world != 1) return fail(DQN_ERR_STATE, "dqn_train_iters is the single-GPU path; with world_size > 1 use "
+                                                  "dqn_actor_step + dqn_update_backward / all-reduce / dqn_update_apply");
+    hipStream_t st = (hipStream_t)stream;
+    const std::vector<int> key{n_iters, env_steps, n_envs, B};
+    return run_captured(h, &h->loop_graphs[key], st, [&] {
+        for (int it = 0; it < n_iters; ++it) {
+            for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st);
+            enqueue_update(h, B, st, st && !h->profiling);
         }
     });
 }

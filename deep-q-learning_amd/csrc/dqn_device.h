@@ -6,6 +6,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for
+// its outstanding global loads / stores (a __syncthreads() would drain prefetches and stores)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 // Mutable scalars that must live on the device so that a hipGraph replay sees them change.
 struct DqnState {
     unsigned long long ring_counter;   // ReplayBuffer._counter      (replay_buffer.py:33)
@@ -19,7 +23,8 @@ struct DqnState {
     float              beta;           // IS exponent for the fused path
     float              lr;
     float              loss;           // last loss
-    float              wmax;           // last batch's max raw IS weight
+    float              wmax;           // max raw IS weight of the batch in flight (atomicMax by the sampler,
+                                       // reset by k_dw once consumed)
     float              epsilon;        // exploration rate of the fused actor step
     float              pad0;
     unsigned int       arrive;         // last-block tickets
@@ -88,3 +93,16 @@ __device__ __forceinline__ float exp2_det(float y) {
 }
 
 __device__ __forceinline__ float pow_det(float x, float a) { return exp2_det(a * log2_det(x)); }
+
+// ------------------------------------------------------------------ diagnostic stamps
+// -DDQN_STAMPS builds (tools only, never shipped): thread 0 of block (0,0) records
+// (s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks) at named points of a kernel.
+#ifdef DQN_STAMPS
+extern __device__ unsigned long long g_stamps[8][64][2];   // [kernel][slot][clock kind]
+#define STAMP(K, S)                                                                         \
+    do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                       \
+             g_stamps[K][S][0] = __builtin_amdgcn_s_memtime();                                \
+             g_stamps[K][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define STAMP(K, S) do { } while (0)
+#endif

@@ -24,6 +24,10 @@ struct FwdPass {
     float *q;              // [B, A] out (may be NULL)
     float *feat;           // [B, H2] row-major out (may be NULL)
     float *px, *ph1, *ph2; // batch-major packed stashes for backward (may be NULL)
+    // optional fused epsilon-greedy policy (q_agent.py:137-141) on the rows of this pass
+    int32_t *act_out;            // [B] or NULL
+    const DqnState *act_state;   // non-NULL: epsilon / counter from the device state
+    float act_eps; unsigned long long act_seed, act_ctr;
 };
 
 struct BwdArgs {
@@ -42,6 +46,10 @@ struct BwdArgs {
     float *loss_part;                  // [ceil(B/16)]
 };
 
+struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU fused path) when P != NULL
+    float *P, *mu, *nu, *pack; int adamw; float b1, b2, eps, wd, grad_scale;
+};
+
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
@@ -52,9 +60,12 @@ void launch_loss(hipStream_t s, const float *pred, const float *targets, const f
 void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
-               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr);
+               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam);
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
+void launch_env_step(hipStream_t s, DqnState *st, float *states, int32_t *actions, float *rewards,
+                     float *observations, uint8_t *dones, long long N, int D, float *tree, long long Ntree, int L,
+                     float *env_obs, const int32_t *env_a, int n, unsigned long long seed, float p_done);
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
                    unsigned long long ctr, int32_t *actions, const DqnState *st_from);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
@@ -76,6 +87,9 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        const float *observations, const uint8_t *dones, int D, int B, float beta,
                        unsigned long long seed, unsigned long long ctr, int from_state,
                        float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw);
+void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
+                             const float *val, int B, int mode, float alpha, float eps);
+void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap);
 void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st);
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
                       int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,

@@ -19,6 +19,13 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DQN_STAMPS
+__device__ unsigned long long g_stamps[8][64][2];
+extern "C" int dqn_debug_stamps(unsigned long long *out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
+
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // position of column c (0..15) inside its 16-block of an LDS A-operand row: the lane group
@@ -87,29 +94,120 @@ void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pa
 
 // ------------------------------------------------------------------- MFMA layer helper
 // acc[t] (t-th 16-column tile of this wave: ct = wave + 4*t) = lds_a[16 x 16*KQ] . packed W
-template <int TN>
-__device__ __forceinline__ void mma_layer(const float *lds_a, int stride, int KQ,
-                                          const float *__restrict__ pack, int CT, int wave, int lane,
-                                          f32x4 (&acc)[TN]) {
+// The packed-weight loads (L2 / Infinity-Cache latency) are software-pipelined PF k-blocks
+// ahead in a ping-pong register buffer. Loads are unconditional (tile / k-block indices are
+// clamped, surplus data is never used) so that they sit in straight-line code and can be issued
+// early -- start() may be called before the activations of the layer exist. The k order of
+// every accumulation chain is unchanged.
+// PF = k-blocks per register chunk. PP = ping-pong two chunks (any KQ); !PP = the whole layer is ONE
+// chunk (requires KQ <= PF: hidden sizes <= 256), so every weight of the layer is in flight at once.
+template <int TN, int PF, bool PP>
+struct MmaLayer {
+    static constexpr int AHEAD = PF >= 16 ? 6 : PF;          // k-blocks requested before finish() (!PP)
+    const float4 *pk[TN];
+    float4 b0[PF][TN], b1[PP ? PF : 1][PP ? TN : 1];
+    int KQ, CT, wave;
+
+    template <int R, int C>
+    __device__ __forceinline__ void load(float4 (&b)[R][C], int kq0) {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *arow = lds_a + (lane & 15) * stride + 4 * (lane >> 4);
-    const float4 *pk = reinterpret_cast<const float4 *>(pack) + lane;
-#pragma unroll 2
-    for (int kq = 0; kq < KQ; ++kq) {
-        const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * kq);
+        for (int p = 0; p < PF; ++p) {
+            int kq = kq0 + p;
+            kq = kq < KQ ? kq : KQ - 1;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const int ct = wave + 4 * t;
-            if (ct < CT) {
-                const float4 b4 = pk[((long long)ct * KQ + kq) * 64];
-                acc[t] = MFMA4(a4.x, b4.x, acc[t]);
-                acc[t] = MFMA4(a4.y, b4.y, acc[t]);
-                acc[t] = MFMA4(a4.z, b4.z, acc[t]);
-                acc[t] = MFMA4(a4.w, b4.w, acc[t]);
+            for (int t = 0; t < TN; ++t) b[p][t] = pk[t][(long long)kq * 64];
+        }
+    }
+    template <int R, int C>
+    __device__ __forceinline__ void compute(const float4 (&b)[R][C], int kq0, const float *arow, f32x4 (&acc)[TN]) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kq = kq0 + p;
+            if (kq < KQ) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * kq);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    acc[t] = MFMA4(a4.x, b[p][t].x, acc[t]);
+                    acc[t] = MFMA4(a4.y, b[p][t].y, acc[t]);
+                    acc[t] = MFMA4(a4.z, b[p][t].z, acc[t]);
+                    acc[t] = MFMA4(a4.w, b[p][t].w, acc[t]);
+                }
             }
         }
     }
+    __device__ __forceinline__ void init(const float *__restrict__ pack, int KQ_, int CT_, int wave_, int lane) {
+        KQ = KQ_; CT = CT_; wave = wave_;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            int ct = wave + 4 * t;
+            ct = ct < CT ? ct : CT - 1;                      // surplus tiles recompute the last one
+            pk[t] = reinterpret_cast<const float4 *>(pack) + (long long)ct * KQ * 64 + lane;
+        }
+    }
+    // issue the loads of k-blocks [P0, P1) of the first chunk (the order of issue is the order of arrival)
+    template <int P0, int P1>
+    __device__ __forceinline__ void load_range() {
+#pragma unroll
+        for (int p = P0; p < P1; ++p) {
+            int kq = p < KQ ? p : KQ - 1;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b0[p][t] = pk[t][(long long)kq * 64];
+        }
+    }
+    // issue the whole first chunk
+    __device__ __forceinline__ void start(const float *__restrict__ pack, int KQ_, int CT_, int wave_, int lane) {
+        init(pack, KQ_, CT_, wave_, lane);
+        load(b0, 0);
+    }
+    // preloaded = every k-block was already requested with load_range<0, PF>()
+    __device__ __forceinline__ void finish(const float *lds_a, int stride, int lane, f32x4 (&acc)[TN], bool preloaded = false) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *arow = lds_a + (lane & 15) * stride + 4 * (lane >> 4);
+        if constexpr (PP) {
+            for (int kq0 = 0; kq0 < KQ; kq0 += 2 * PF) {
+                load(b1, kq0 + PF);
+                compute(b0, kq0, arow, acc);
+                load(b0, kq0 + 2 * PF);
+                compute(b1, kq0 + PF, arow, acc);
+            }
+        } else {
+            // single chunk; k-blocks [0, AHEAD) were requested by load_range<0, AHEAD>() long ago, block
+            // p + AHEAD is requested right before block p is multiplied: the address traffic of the layer
+            // is spread between the MFMAs instead of blocking the wave's issue in one burst
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                if (p < KQ) {
+                    if (p + AHEAD < PF && !preloaded) {
+                        const int kq = p + AHEAD < KQ ? p + AHEAD : KQ - 1;
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) b0[p + AHEAD < PF ? p + AHEAD : 0][t] = pk[t][(long long)kq * 64];
+                    }
+                    const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * p);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        acc[t] = MFMA4(a4.x, b0[p][t].x, acc[t]);
+                        acc[t] = MFMA4(a4.y, b0[p][t].y, acc[t]);
+                        acc[t] = MFMA4(a4.z, b0[p][t].z, acc[t]);
+                        acc[t] = MFMA4(a4.w, b0[p][t].w, acc[t]);
+                    }
+                }
+            }
+        }
+    }
+};
+
+// Agent._policy (q_agent.py:137-141): greedy iff eps < U(0,1) else randint(0, A);
+// compute_action (q_learning_functions.py:70): argmax, first max wins.
+__device__ __forceinline__ int policy_row(const float *q, int A, float epsilon, unsigned long long seed,
+                                          unsigned long long ctr, int i) {
+    const u32x4 o = philox_draw(seed, ctr, (uint32_t)i, DQN_STREAM_POLICY);
+    if (epsilon < u01(o.x)) {
+        int act = 0;
+        for (int k = 1; k < A; ++k) if (q[k] > q[act]) act = k;
+        return act;
+    }
+    return (int)(((unsigned long long)o.y * (unsigned long long)A) >> 32);
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -129,26 +227,63 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B) {
     const int sx = K1 + 4, s1 = m.H1 + 4, s2 = m.H2 + 4;
     float *lx = lds, *l1 = lx + 16 * sx, *l2 = l1 + 16 * s1, *lh = l2 + 16 * s2;   // lh: [16][16]
 
+    STAMP(0, 0);
+    // Vector-memory returns are in order, so the order of issue is the order of arrival: the 16 input
+    // rows first, then layer-1 weights + biases, then all of layer 2 and the heads (they stream in
+    // while layer 1 runs; nothing below waits for more than it needs).
+    float xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = tid + 256 * u;
+        const int rl = t / K1, c = t - rl * K1;
+        xv[u] = (t < 16 * K1 && row0 + rl < B && c < m.D) ? ps.x[(long long)(row0 + rl) * m.D + c] : 0.0f;
+    }
+    MmaLayer<TN1, 2, true> L1; MmaLayer<TN2, 16, false> L2; MmaLayer<1, 16, false> LH;
+    L1.start(ps.pack + m.p_w1, m.KQ1, m.H1 / 16, wave, lane);
+    float bias1[TN1], bias2[TN2], biash = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TN1; ++t) { int ct = wave + 4 * t; ct = ct < m.H1 / 16 ? ct : m.H1 / 16 - 1; bias1[t] = ps.params[m.o_b1 + 16 * ct + (lane & 15)]; }
+#pragma unroll
+    for (int t = 0; t < TN2; ++t) { int ct = wave + 4 * t; ct = ct < m.H2 / 16 ? ct : m.H2 / 16 - 1; bias2[t] = ps.params[m.o_b2 + 16 * ct + (lane & 15)]; }
+    if (wave == 0) {
+        const int c = lane & 15;
+        if (c == 0) biash = ps.params[m.o_bv];
+        else if (c <= m.A) biash = ps.params[m.o_ba + c - 1];
+    }
+    L2.init(ps.pack + m.p_w2, m.H1 / 16, m.H2 / 16, wave, lane);
+    L2.template load_range<0, 6>();                          // the first AHEAD k-blocks; the rest interleave with the MFMAs
+    if (wave == 0) LH.init(ps.pack + m.p_wh, m.H2 / 16, 1, 0, lane);
+
     // stage the 16 input rows (zero-padded) in A-operand order
-    for (int t = tid; t < 16 * K1; t += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = tid + 256 * u;
+        if (t < 16 * K1) {
+            const int rl = t / K1, c = t - rl * K1;
+            lx[rl * sx + (c & ~15) + perm16(c & 15)] = xv[u];
+            if (ps.px) ps.px[pidx(KQb, row0 + rl, c)] = xv[u];
+        }
+    }
+    for (int t = tid + 1024; t < 16 * K1; t += 256) {            // obs_dim > 64 only
         const int rl = t / K1, c = t - rl * K1;
         float v = 0.0f;
         if (row0 + rl < B && c < m.D) v = ps.x[(long long)(row0 + rl) * m.D + c];
         lx[rl * sx + (c & ~15) + perm16(c & 15)] = v;
         if (ps.px) ps.px[pidx(KQb, row0 + rl, c)] = v;
     }
-    __syncthreads();
+    LDS_BARRIER();
+    STAMP(0, 1);
 
     // layer 1: h1 = relu(x @ w1 + b1)                                      dddqn.py:25-26
     {
         f32x4 acc[TN1];
-        mma_layer<TN1>(lx, sx, m.KQ1, ps.pack + m.p_w1, m.H1 / 16, wave, lane, acc);
+        L1.finish(lx, sx, lane, acc);
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int ct = wave + 4 * t;
             if (ct < m.H1 / 16) {
                 const int c = lane & 15, col = 16 * ct + c;
-                const float bias = ps.params[m.o_b1 + col];
+                const float bias = bias1[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = 4 * (lane >> 4) + r;
@@ -160,18 +295,21 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B) {
             }
         }
     }
-    __syncthreads();
+    if (wave == 0) LH.template load_range<0, 16>();          // heads' weights: wave 0 only, 16 requests
+    LDS_BARRIER();
+    STAMP(0, 2);
 
     // layer 2: h2 = relu(h1 @ w2 + b2)                                     dddqn.py:27-28
     {
         f32x4 acc[TN2];
-        mma_layer<TN2>(l1, s1, m.H1 / 16, ps.pack + m.p_w2, m.H2 / 16, wave, lane, acc);
+        L2.finish(l1, s1, lane, acc);
+        STAMP(0, 3);
 #pragma unroll
         for (int t = 0; t < TN2; ++t) {
             const int ct = wave + 4 * t;
             if (ct < m.H2 / 16) {
                 const int c = lane & 15, col = 16 * ct + c;
-                const float bias = ps.params[m.o_b2 + col];
+                const float bias = bias2[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = 4 * (lane >> 4) + r;
@@ -184,29 +322,35 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B) {
             }
         }
     }
-    __syncthreads();
+    LDS_BARRIER();
+    STAMP(0, 4);
 
     // heads: column 0 = val (dddqn.py:29), columns 1..A = adv (:30); one 16-column tile
     if (wave == 0) {
         f32x4 acc[1];
-        mma_layer<1>(l2, s2, m.H2 / 16, ps.pack + m.p_wh, 1, 0, lane, acc);
+        LH.finish(l2, s2, lane, acc, true);
         const int c = lane & 15;
-        float bias = 0.0f;
-        if (c == 0) bias = ps.params[m.o_bv];
-        else if (c <= m.A) bias = ps.params[m.o_ba + c - 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[0][r] + bias;
+        for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[0][r] + biash;
     }
-    __syncthreads();
+    LDS_BARRIER();
+    STAMP(0, 5);
 
     // Q = val + adv - mean(adv)                                            dddqn.py:31
-    if (tid < 16 && row0 + tid < B && ps.q) {
+    if (tid < 16 && row0 + tid < B) {
         const float *hr = lh + tid * 16;
-        float sum = 0.0f;
+        float sum = 0.0f, qrow[16];
         for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
         const float mean = __fdiv_rn(sum, (float)m.A);
-        for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = (hr[0] + hr[1 + a]) - mean;
+        for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
+        if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
+        if (ps.act_out) {
+            const float eps = ps.act_state ? ps.act_state->epsilon : ps.act_eps;
+            const unsigned long long ctr = ps.act_state ? ps.act_state->env_ctr : ps.act_ctr;
+            ps.act_out[row0 + tid] = policy_row(qrow, m.A, eps, ps.act_seed, ctr, row0 + tid);
+        }
     }
+    STAMP(0, 6);
 }
 
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
@@ -333,65 +477,74 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
     const int s3 = 16 + 4, s2 = m.H2 + 4;
     float *l3 = lds, *l2 = l3 + 16 * s3, *lrow = l2 + 16 * s2;     // lrow[16]: per-row loss
 
-    // max raw IS weight over the batch (order-independent), for w_i / max_j w_j
-    float wmax = 1.0f;
-    if (g.w_raw) {
-        float mx = 0.0f;
-        for (int j = tid; j < B; j += 256) mx = fmaxf(mx, g.w_raw[j]);
-        red[tid] = mx;
-        __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) {
-            if (tid < sft) red[tid] = fmaxf(red[tid], red[tid + sft]);
-            __syncthreads();
+    STAMP(5, 0);
+    // In-order returns again: the few scattered TD inputs of the 16 row-threads are issued FIRST,
+    // then the transposed-weight chunks and the post-ReLU activations that gate the ReLU derivatives.
+    const int irow = row0 + tid;
+    const bool rowt = tid < 16 && irow < B;
+    float qr[16], tr[16], nqr[16], ntr[16];
+    int ai = 0; float ri = 0.0f, di = 0.0f, wi = 1.0f, wmax = 1.0f;
+    if (rowt) {
+        for (int k2 = 0; k2 < A; ++k2) qr[k2] = g.q[(long long)irow * A + k2];
+        if (g.a) ai = g.a[irow];
+        if (g.targets) {
+            for (int k2 = 0; k2 < A; ++k2) tr[k2] = g.targets[(long long)irow * A + k2];
+        } else {
+            for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = g.nq[(long long)irow * A + k2]; ntr[k2] = g.nt[(long long)irow * A + k2]; }
+            ri = g.r[irow];
+            di = g.d_f32 ? g.d_f32[irow] : (g.d_u8[irow] ? 1.0f : 0.0f);       // preprocessing :84
         }
-        wmax = red[0];
-        if (tile == 0 && tid == 0) st->wmax = wmax;
+        if (g.w_raw) { wi = g.w_raw[irow]; wmax = st->wmax; }     // batch max: atomicMax'ed by the sampler
+        else if (g.isw) wi = g.isw[irow];
     }
-
+    MmaLayer<TN2, 1, false> LA; MmaLayer<TN1, 16, false> LB;
+    LA.start(g.pack + m.p_wht, 1, m.H2 / 16, wave, lane);
+    float m2[TN2][4], m1[TN1][4];
+#pragma unroll
+    for (int t = 0; t < TN2; ++t) {
+        int ct = wave + 4 * t; ct = ct < m.H2 / 16 ? ct : m.H2 / 16 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m2[t][r] = g.ph2[pidx(KQb, row0 + 4 * (lane >> 4) + r, 16 * ct + (lane & 15))];
+    }
+    LB.init(g.pack + m.p_w2t, m.H2 / 16, m.H1 / 16, wave, lane);
+    LB.template load_range<0, 6>();
+    STAMP(5, 1);
     for (int t = tid; t < 16 * s3; t += 256) l3[t] = 0.0f;
-    __syncthreads();
+    LDS_BARRIER();
 
     if (tid < 16) {
-        const int i = row0 + tid;
         float rowloss = 0.0f;
-        if (i < B) {
-            float qr[16], tr[16];
-            for (int k = 0; k < A; ++k) qr[k] = g.q[(long long)i * A + k];
-            float delta = 0.0f;
-            const int ai = g.a ? g.a[i] : 0;
-            if (g.targets) {
-                for (int k = 0; k < A; ++k) tr[k] = g.targets[(long long)i * A + k];
-            } else {
-                float nqr[16], ntr[16];
-                for (int k = 0; k < A; ++k) { nqr[k] = g.nq[(long long)i * A + k]; ntr[k] = g.nt[(long long)i * A + k]; }
-                const float df = g.d_f32 ? g.d_f32[i] : (g.d_u8[i] ? 1.0f : 0.0f);     // preprocessing :84
-                delta = td_row(qr, nqr, ntr, ai, g.r[i], df, g.gamma, A, tr);
+        if (rowt) {
+            const int i = irow;
+            if (!g.targets) {
+                const float delta = td_row(qr, nqr, ntr, ai, ri, di, g.gamma, A, tr);
                 if (g.td) g.td[i] = delta;
                 if (g.td_abs) g.td_abs[i] = fabsf(delta);
             }
             float w = 1.0f;
-            if (g.w_raw) { w = __fdiv_rn(g.w_raw[i], wmax); if (g.isw_out) g.isw_out[i] = w; }
-            else if (g.isw) w = g.isw[i];
+            if (g.w_raw) { w = __fdiv_rn(wi, wmax); if (g.isw_out) g.isw_out[i] = w; }
+            else if (g.isw) w = wi;
             const float invB = __fdiv_rn(1.0f, (float)B);
             float gk[16], gsum = 0.0f;
-            for (int k = 0; k < A; ++k) {
-                const float e = qr[k] - tr[k];                 // pred - target, pred == q   (:35)
+            for (int k2 = 0; k2 < A; ++k2) {
+                const float e = qr[k2] - tr[k2];               // pred - target, pred == q   (:35)
                 rowloss = rowloss + huber(e);                  // :36
                 const float c = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
-                gk[k] = (w * c) * invB;                        // dL/dpred
-                gsum = gsum + gk[k];
-                if (g.dq) g.dq[(long long)i * A + k] = gk[k];
-                if (g.targets_out) g.targets_out[(long long)i * A + k] = tr[k];
+                gk[k2] = (w * c) * invB;                       // dL/dpred
+                gsum = gsum + gk[k2];
+                if (g.dq) g.dq[(long long)i * A + k2] = gk[k2];
+                if (g.targets_out) g.targets_out[(long long)i * A + k2] = tr[k2];
             }
             if (g.w_raw || g.isw) rowloss = w * rowloss;
             // dueling backward: dv = sum_a g_a ; dadv_j = g_j - (1/A) sum_a g_a
             const float gmean = __fdiv_rn(gsum, (float)A);
             l3[tid * s3 + perm16(0)] = gsum;
-            for (int k = 0; k < A; ++k) l3[tid * s3 + perm16(1 + k)] = gk[k] - gmean;
+            for (int k2 = 0; k2 < A; ++k2) l3[tid * s3 + perm16(1 + k2)] = gk[k2] - gmean;
         }
         lrow[tid] = rowloss;
     }
-    __syncthreads();
+    LDS_BARRIER();
+    STAMP(5, 2);
     if (tid == 0) {
         float s = 0.0f;
         for (int k = 0; k < 16; ++k) s = s + lrow[k];
@@ -406,7 +559,7 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
     // dz2 = (dz3 . WH^T) * (h2 > 0)
     {
         f32x4 acc[TN2];
-        mma_layer<TN2>(l3, s3, 1, g.pack + m.p_wht, m.H2 / 16, wave, lane, acc);
+        LA.finish(l3, s3, lane, acc);
 #pragma unroll
         for (int t = 0; t < TN2; ++t) {
             const int ct = wave + 4 * t;
@@ -415,20 +568,27 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = 4 * (lane >> 4) + r;
-                    const long long pi = pidx(KQb, row0 + rl, col);
-                    const float v = g.ph2[pi] > 0.0f ? acc[t][r] : 0.0f;
+                    const float v = m2[t][r] > 0.0f ? acc[t][r] : 0.0f;
                     l2[rl * s2 + 16 * ct + perm16(c)] = v;
-                    g.pdz2[pi] = v;
+                    g.pdz2[pidx(KQb, row0 + rl, col)] = v;
                 }
             }
         }
     }
-    __syncthreads();
+    // the layer-1 ReLU gates (the rest of W2^T is requested between the MFMAs below)
+#pragma unroll
+    for (int t = 0; t < TN1; ++t) {
+        int ct = wave + 4 * t; ct = ct < m.H1 / 16 ? ct : m.H1 / 16 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m1[t][r] = g.ph1[pidx(KQb, row0 + 4 * (lane >> 4) + r, 16 * ct + (lane & 15))];
+    }
+    LDS_BARRIER();
+    STAMP(5, 3);
 
     // dz1 = (dz2 . W2^T) * (h1 > 0)
     {
         f32x4 acc[TN1];
-        mma_layer<TN1>(l2, s2, m.H2 / 16, g.pack + m.p_w2t, m.H1 / 16, wave, lane, acc);
+        LB.finish(l2, s2, lane, acc);
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int ct = wave + 4 * t;
@@ -437,12 +597,12 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = 4 * (lane >> 4) + r;
-                    const long long pi = pidx(KQb, row0 + rl, col);
-                    g.pdz1[pi] = g.ph1[pi] > 0.0f ? acc[t][r] : 0.0f;
+                    g.pdz1[pidx(KQb, row0 + rl, col)] = m1[t][r] > 0.0f ? acc[t][r] : 0.0f;
                 }
             }
         }
     }
+    STAMP(5, 4);
 }
 
 void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st) {
@@ -455,6 +615,55 @@ void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, D
 #undef BWD_CASE
 }
 
+// ---------------------------------------------------------------------------- optimizer
+// optax scale_by_adam -> add_decayed_weights (adamw) -> scale(-lr) -> apply_updates for ONE element,
+// plus the refresh of that element's slots in the fragment-packed shadows. One IEEE rounding per
+// written operation: bit-exact against the CPU restatement.
+struct AdamCoef { float c1, c2, omb1, omb2, neglr; };
+
+__device__ __forceinline__ AdamCoef adam_coef(const DqnState *st, float b1, float b2, double *b1pow, double *b2pow) {
+    *b1pow = st->b1pow * (double)b1; *b2pow = st->b2pow * (double)b2;
+    return AdamCoef{(float)(1.0 - *b1pow), (float)(1.0 - *b2pow), 1.0f - b1, 1.0f - b2, -st->lr};
+}
+
+__device__ __forceinline__ float adam_elem(const AdamCoef &c, float g, float *P, float *mu, float *nu, int i,
+                                           int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
+    const float gi = g * grad_scale;
+    const float mm = (b1 * mu[i]) + (c.omb1 * gi);
+    const float vv = (b2 * nu[i]) + (c.omb2 * (gi * gi));
+    mu[i] = mm; nu[i] = vv;
+    const float mhat = __fdiv_rn(mm, c.c1), vhat = __fdiv_rn(vv, c.c2);
+    float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + eps);
+    float p = P[i];
+    if (adamw) u = u + (wd * p);
+    p = p + (c.neglr * u);
+    P[i] = p;
+    return p;
+}
+
+__device__ __forceinline__ void scatter_packs(const NetDims &m, int i, float v, float *pack) {
+    const int o_b1 = (int)m.o_b1, o_w2 = (int)m.o_w2, o_b2 = (int)m.o_b2, o_wv = (int)m.o_wv, o_bv = (int)m.o_bv,
+              o_wa = (int)m.o_wa, o_ba = (int)m.o_ba;
+    if (i < o_b1) {                                     // w1[k][n]
+        const int k = i / m.H1, n = i - k * m.H1;
+        pack[m.p_w1 + pidx(m.KQ1, k, n)] = v;
+    } else if (i >= o_w2 && i < o_b2) {                 // w2[k][n]
+        const int u = i - o_w2;
+        const int k = u / m.H2, n = u - k * m.H2;
+        pack[m.p_w2 + pidx(m.H1 / 16, k, n)] = v;
+        pack[m.p_w2t + pidx(m.H2 / 16, n, k)] = v;
+    } else if (i >= o_wv && i < o_bv) {                 // wv[k]
+        const int k = i - o_wv;
+        pack[m.p_wh + pidx(m.H2 / 16, k, 0)] = v;
+        pack[m.p_wht + pidx(1, 0, k)] = v;
+    } else if (i >= o_wa && i < o_ba) {                 // wa[k][a]
+        const int u = i - o_wa;
+        const int k = u / m.A, a = u - k * m.A;
+        pack[m.p_wh + pidx(m.H2 / 16, k, 1 + a)] = v;
+        pack[m.p_wht + pidx(1, 1 + a, k)] = v;
+    }
+}
+
 // ------------------------------------------------------------------ weight gradients
 // dW = H^T . Z over the batch: one workgroup per 16x16 tile of one weight block, the batch
 // (K) split over its 4 waves and combined through LDS in a fixed order (deterministic).
@@ -462,7 +671,7 @@ void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, D
 __global__ void __launch_bounds__(256)
 k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, const float *__restrict__ ph2,
      const float *__restrict__ pdz1, const float *__restrict__ pdz2, const float *__restrict__ pdz3, int B,
-     float *grad, const float *loss_part, float *loss_out, DqnState *st, int bump_ctr) {
+     float *grad, const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, AdamArgs ad) {
     __shared__ float red[4][64][4];
     __shared__ float redb[4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -474,142 +683,175 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     else if ((b -= MT2 * NT2) < MT1 * NT1) { which = 1; mt = b / NT1; nt = b % NT1; pa = px;  pb = pdz1; }
     else                                 { b -= MT1 * NT1; which = 3; mt = b; nt = 0; pa = ph2; pb = pdz3; (void)MTH; }
 
+    STAMP(6, 0);
+    // Which parameter(s) will this thread update? One tile element (row tid/16, col tid%16), and for the
+    // mt == 0 tiles threads 0..15 also own a bias element. Their P / mu / nu and the step coefficients do
+    // not depend on the gradient: fetch them now, the MFMA loop hides the latency.
+    int ei[2] = {-1, -1};
+    {
+        const int rr = tid >> 4, c = tid & 15, n = 16 * nt + c, mrow = 16 * mt + rr;
+        if (which == 2) ei[0] = (int)m.o_w2 + mrow * m.H2 + n;
+        else if (which == 1) { if (mrow < m.D) ei[0] = (int)m.o_w1 + mrow * m.H1 + n; }
+        else { if (n == 0) ei[0] = (int)m.o_wv + mrow; else if (n <= m.A) ei[0] = (int)m.o_wa + mrow * m.A + (n - 1); }
+        if (mt == 0 && tid < 16) {
+            if (which == 2) ei[1] = (int)m.o_b2 + n;
+            else if (which == 1) ei[1] = (int)m.o_b1 + n;
+            else { if (n == 0) ei[1] = (int)m.o_bv; else if (n <= m.A) ei[1] = (int)m.o_ba + n - 1; }
+        }
+    }
+    double b1pow = 0.0, b2pow = 0.0;
+    AdamCoef co{};
+    float pP[2] = {0.f, 0.f}, pM[2] = {0.f, 0.f}, pV[2] = {0.f, 0.f};
+    if (ad.P) {
+        co = adam_coef(st, ad.b1, ad.b2, &b1pow, &b2pow);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (ei[e] >= 0) { pP[e] = ad.P[ei[e]]; pM[e] = ad.mu[ei[e]]; pV[e] = ad.nu[ei[e]]; }
+    }
     const int per = (KQb + 3) / 4;
     const int k0 = wave * per, k1 = (k0 + per < KQb) ? k0 + per : KQb;
     const float4 *A4 = reinterpret_cast<const float4 *>(pa) + ((long long)mt * KQb) * 64 + lane;
     const float4 *B4 = reinterpret_cast<const float4 *>(pb) + ((long long)nt * KQb) * 64 + lane;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
-#pragma unroll 4
-    for (int kq = k0; kq < k1; ++kq) {
-        const float4 a4 = A4[(long long)kq * 64], b4 = B4[(long long)kq * 64];
-        acc = MFMA4(a4.x, b4.x, acc);
-        acc = MFMA4(a4.y, b4.y, acc);
-        acc = MFMA4(a4.z, b4.z, acc);
-        acc = MFMA4(a4.w, b4.w, acc);
-        bsum = (((bsum + b4.x) + b4.y) + b4.z) + b4.w;
+    // operand loads pipelined 8 k-blocks ahead (ping-pong); chain order over the batch unchanged
+    constexpr int PF = 8;
+    float4 a0[PF], c0[PF], a1[PF], c1[PF];
+    auto load = [&](float4 (&a)[PF], float4 (&c)[PF], int kq0) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            int kq = kq0 + p;
+            kq = kq < KQb ? kq : KQb - 1;                     // unconditional, clamped: surplus never used
+            a[p] = A4[(long long)kq * 64]; c[p] = B4[(long long)kq * 64];
+        }
+    };
+    auto compute = [&](const float4 (&a)[PF], const float4 (&c)[PF], int kq0) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (kq0 + p < k1) {
+                acc = MFMA4(a[p].x, c[p].x, acc);
+                acc = MFMA4(a[p].y, c[p].y, acc);
+                acc = MFMA4(a[p].z, c[p].z, acc);
+                acc = MFMA4(a[p].w, c[p].w, acc);
+                bsum = (((bsum + c[p].x) + c[p].y) + c[p].z) + c[p].w;
+            }
+    };
+    load(a0, c0, k0);
+    for (int kq0 = k0; kq0 < k1; kq0 += 2 * PF) {
+        load(a1, c1, kq0 + PF);
+        compute(a0, c0, kq0);
+        load(a0, c0, kq0 + 2 * PF);
+        compute(a1, c1, kq0 + PF);
     }
+    STAMP(6, 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
     redb[wave][lane] = bsum;
-    __syncthreads();
-    if (wave == 0) {
-        const int c = lane & 15, n = 16 * nt + c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = ((red[0][lane][r] + red[1][lane][r]) + red[2][lane][r]) + red[3][lane][r];
-            const int mrow = 16 * mt + 4 * (lane >> 4) + r;
-            if (which == 2) grad[m.o_w2 + (long long)mrow * m.H2 + n] = v;
-            else if (which == 1) { if (mrow < m.D) grad[m.o_w1 + (long long)mrow * m.H1 + n] = v; }
-            else { if (n == 0) grad[m.o_wv + mrow] = v; else if (n <= m.A) grad[m.o_wa + (long long)mrow * m.A + (n - 1)] = v; }
-        }
-        if (mt == 0 && lane < 16) {
-            float s = 0.0f;
+    LDS_BARRIER();
+    // reduce the four K-slices in wave order (fixed => deterministic), then write / apply
+    {
+        const int rr = tid >> 4, c = tid & 15;
+        const int sl = ((rr >> 2) << 4) | c, sr = rr & 3;           // accumulator lane / register holding it
+        float gv[2];
+        gv[0] = ((red[0][sl][sr] + red[1][sl][sr]) + red[2][sl][sr]) + red[3][sl][sr];
+        gv[1] = 0.0f;
+        if (ei[1] >= 0)
             for (int w = 0; w < 4; ++w)
-                for (int gq = 0; gq < 4; ++gq) s = s + redb[w][16 * gq + lane];
-            if (which == 2) grad[m.o_b2 + n] = s;
-            else if (which == 1) grad[m.o_b1 + n] = s;
-            else { if (n == 0) grad[m.o_bv] = s; else if (n <= m.A) grad[m.o_ba + n - 1] = s; }
+                for (int gq = 0; gq < 4; ++gq) gv[1] = gv[1] + redb[w][16 * gq + tid];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = ei[e];
+            if (i < 0) continue;
+            grad[i] = gv[e];
+            if (ad.P) {
+                // optax scale_by_adam -> add_decayed_weights -> scale(-lr) -> apply_updates (as adam_elem)
+                const float gi = gv[e] * ad.grad_scale;
+                const float mm = (ad.b1 * pM[e]) + (co.omb1 * gi);
+                const float vv = (ad.b2 * pV[e]) + (co.omb2 * (gi * gi));
+                ad.mu[i] = mm; ad.nu[i] = vv;
+                const float mhat = __fdiv_rn(mm, co.c1), vhat = __fdiv_rn(vv, co.c2);
+                float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + ad.eps);
+                float pnew = pP[e];
+                if (ad.adamw) u = u + (ad.wd * pnew);
+                pnew = pnew + (co.neglr * u);
+                ad.P[i] = pnew;
+                scatter_packs(m, i, pnew, ad.pack);
+            }
         }
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    STAMP(6, 2);
+    if (blockIdx.x == 0 && wave == 1) {
+        // loss = (sum of the per-tile partial sums) / B: lanes load in parallel, fixed shuffle tree
         float s = 0.0f;
-        for (int t = 0; t < KQb; ++t) s = s + loss_part[t];
-        const float L = __fdiv_rn(s, (float)B);
-        st->loss = L;
-        if (loss_out) *loss_out = L;
-        if (bump_ctr) st->sample_ctr += 1ull;
+        for (int t = lane; t < KQb; t += 64) s = s + loss_part[t];
+        for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            const float Lv = __fdiv_rn(s, (float)B);
+            st->loss = Lv;
+            if (loss_out) *loss_out = Lv;
+            if (bump_ctr) { st->sample_ctr += 1ull; st->wmax = 0.0f; }
+        }
     }
+    if (ad.P) {
+        // commit the optimizer counters once every block has read them (its element updates above
+        // depend on the coefficients, so passing this barrier implies the reads are complete)
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned int ticket = atomicAdd(&st->arrive, 1u);
+            if (ticket == gridDim.x - 1) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
+        }
+    }
+    STAMP(6, 3);
 }
 
 void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
-               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr) {
+               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam) {
     const int tiles = (m.H1 / 16) * (m.H2 / 16) + m.KQ1 * (m.H1 / 16) + m.H2 / 16;
     hipLaunchKernelGGL(k_dw, dim3(tiles), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, B, grad,
-                       loss_part, loss_out, st, bump_ctr);
+                       loss_part, loss_out, st, bump_ctr, adam);
 }
 
 // ---------------------------------------------------------------------------- optimizer
 // optax scale_by_adam -> add_decayed_weights (adamw) -> scale(-lr) -> apply_updates, and the
 // refresh of the fragment-packed shadows in the same pass. Bit-exact vs the CPU restatement.
-__device__ __forceinline__ void scatter_packs(const NetDims &m, long long i, float v, float *pack) {
-    if (i < m.o_b1) {                                   // w1[k][n]
-        const int k = (int)(i / m.H1), n = (int)(i % m.H1);
-        pack[m.p_w1 + pidx(m.KQ1, k, n)] = v;
-    } else if (i >= m.o_w2 && i < m.o_b2) {             // w2[k][n]
-        const long long u = i - m.o_w2;
-        const int k = (int)(u / m.H2), n = (int)(u % m.H2);
-        pack[m.p_w2 + pidx(m.H1 / 16, k, n)] = v;
-        pack[m.p_w2t + pidx(m.H2 / 16, n, k)] = v;
-    } else if (i >= m.o_wv && i < m.o_bv) {             // wv[k]
-        const int k = (int)(i - m.o_wv);
-        pack[m.p_wh + pidx(m.H2 / 16, k, 0)] = v;
-        pack[m.p_wht + pidx(1, 0, k)] = v;
-    } else if (i >= m.o_wa && i < m.o_ba) {             // wa[k][a]
-        const long long u = i - m.o_wa;
-        const int k = (int)(u / m.A), a = (int)(u % m.A);
-        pack[m.p_wh + pidx(m.H2 / 16, k, 1 + a)] = v;
-        pack[m.p_wht + pidx(1, 1 + a, k)] = v;
-    }
-}
-
 __global__ void __launch_bounds__(256)
 k_adam(NetDims m, DqnState *st, float *P, const float *__restrict__ g, float *mu, float *nu, float *pack,
        int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
-    const double b1pow = st->b1pow * (double)b1, b2pow = st->b2pow * (double)b2;
-    const float c1 = (float)(1.0 - b1pow), c2 = (float)(1.0 - b2pow);
-    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2, neglr = -st->lr;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m.P; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * grad_scale;
-        const float mm = (b1 * mu[i]) + (omb1 * gi);
-        const float vv = (b2 * nu[i]) + (omb2 * (gi * gi));
-        mu[i] = mm; nu[i] = vv;
-        const float mhat = __fdiv_rn(mm, c1), vhat = __fdiv_rn(vv, c2);
-        float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + eps);
-        float p = P[i];
-        if (adamw) u = u + (wd * p);
-        p = p + (neglr * u);
-        P[i] = p;
+    double b1pow, b2pow;
+    const AdamCoef co = adam_coef(st, b1, b2, &b1pow, &b2pow);
+    const int nP = (int)m.P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nP; i += gridDim.x * blockDim.x) {
+        const float p = adam_elem(co, g[i], P, mu, nu, i, adamw, b1, b2, eps, wd, grad_scale);
         scatter_packs(m, i, p, pack);
     }
-    __threadfence();
+    // commit the step counters once every block has read them: a thread's stores above depend on
+    // the coefficients, so passing this barrier implies its reads of the state are complete.
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int ticket = atomicAdd(&st->arrive, 1u);
-        if (ticket == gridDim.x - 1) {
-            st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0;
-            __threadfence();
-        }
+        if (ticket == gridDim.x - 1) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
     }
 }
 
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
     int blocks = (int)((m.P + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, m, st, params, grad, mu, nu, pack, adamw, b1, b2,
                        eps, wd, grad_scale);
 }
 
 // ----------------------------------------------------------------------- epsilon-greedy
-// Agent._policy (q_agent.py:137-141): greedy iff eps < U(0,1) else randint(0, A);
-// compute_action (q_learning_functions.py:70): argmax, first max wins.
 __global__ void __launch_bounds__(256)
 k_policy(const float *__restrict__ q, int n, int A, float epsilon, unsigned long long seed,
          unsigned long long ctr, int32_t *actions, const DqnState *st_from) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (st_from) { epsilon = st_from->epsilon; ctr = st_from->env_ctr; }
-    const u32x4 o = philox_draw(seed, ctr, (uint32_t)i, DQN_STREAM_POLICY);
-    int act;
-    if (epsilon < u01(o.x)) {
-        act = 0;
-        for (int k = 1; k < A; ++k) if (q[(long long)i * A + k] > q[(long long)i * A + act]) act = k;
-    } else {
-        act = (int)(((unsigned long long)o.y * (unsigned long long)A) >> 32);
-    }
-    actions[i] = act;
+    float qrow[16];
+    for (int k = 0; k < A; ++k) qrow[k] = q[(long long)i * A + k];
+    actions[i] = policy_row(qrow, A, epsilon, seed, ctr, i);
 }
 
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,

@@ -201,6 +201,11 @@ class Engine:
         idx, td_abs = self.dev(idx, torch.int32), self.dev(td_abs, torch.float32)
         L.check(self.lib.dqn_per_update(self.h, _ptr(idx), _ptr(td_abs), idx.numel(), self._s()))
 
+    def per_update_sorted(self, idx, td_abs):
+        """as per_update, for non-decreasing idx (the output of per_sample); runs on many CUs"""
+        idx, td_abs = self.dev(idx, torch.int32), self.dev(td_abs, torch.float32)
+        L.check(self.lib.dqn_per_update_sorted(self.h, _ptr(idx), _ptr(td_abs), idx.numel(), self._s()))
+
     def per_set(self, idx, prio):
         idx, prio = self.dev(idx, torch.int32), self.dev(prio, torch.float32)
         L.check(self.lib.dqn_per_set(self.h, _ptr(idx), _ptr(prio), idx.numel(), self._s()))
@@ -293,6 +298,10 @@ class Engine:
     def actor_step(self, stream=None):
         """one vector env step (q_agent.py:176-183) on the device-resident synthetic envs"""
         L.check(self.lib.dqn_actor_step(self.h, self.n_envs, self._s(stream)))
+
+    def train_iters(self, n_iters, env_steps, B, stream=None):
+        """n_iters x (env_steps vector env steps + one update) in one graph launch (q_agent.py:174-187)"""
+        L.check(self.lib.dqn_train_iters(self.h, n_iters, env_steps, getattr(self, "n_envs", 0), B, self._s(stream)))
 
     # ------------------------------------------------------------------ profiling
     def profile_begin(self, stream=None):

@@ -111,6 +111,9 @@ int dqn_per_sample(dqn_handle *h, int32_t B, float beta, uint64_t seed, uint64_t
  * recomputed as left + right. */
 int dqn_per_update(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream);
 int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream);
+/* same result as dqn_per_update for NON-DECREASING idx (what dqn_per_sample returns): spread over many
+ * CUs, siblings and duplicates resolved between adjacent positions. Undefined for unsorted idx. */
+int dqn_per_update_sorted(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream);
 
 /* Model.__call__ (LunarLander/dddqn.py:24-34): q[B,A]; feat (optional) = the H2
  * features of return_features=True (:32-33). */
@@ -161,6 +164,10 @@ int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, uint64_t se
 int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream);
 int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream);
 int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
+/* the reference's inner loop (q_agent.py:174-187) for n_iters iterations as ONE hipGraph launch:
+ * each iteration = env_steps vector env steps (train_frequency) followed by one Agent._step.
+ * Single-GPU path (world_size == 1). */
+int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps, int32_t n_envs, int32_t B, void *stream);
 
 /* Agent._update_target_model (q_agent.py:143-144) */
 int dqn_sync_target(dqn_handle *h, void *stream);

@@ -245,6 +245,14 @@ def test_per_bitexact(dq, L_, n_add, B):
         ct.update(upd, td); e.per_update(upd, td)
         t = tree()
         assert np.array_equal(t.view(np.uint32), ct.tree.view(np.uint32))
+        # the many-CU write-back for sorted indices (what the fused update uses), duplicates included
+        _, idx2, _ = e.per_sample(B, beta, seed=10, ctr=it)
+        ci2, _ = ct.sample(cr.size, B, beta, 10, it)
+        assert np.array_equal(host(idx2), ci2) and np.all(np.diff(ci2) >= 0)
+        td2 = (np.abs(rng.standard_normal(B)) * 2).astype(np.float32)
+        ct.update(ci2, td2); e.per_update_sorted(ci2, td2)
+        t = tree()
+        assert np.array_equal(t.view(np.uint32), ct.tree.view(np.uint32))
     k = np.arange(1, N)
     assert np.array_equal(t[k], t[2 * k] + t[2 * k + 1])                     # size-independent invariant
     e.close()
@@ -365,3 +373,39 @@ def test_profile_hooks_and_error_paths(dq):
     with pytest.raises(dq._lib.DqnError):
         mk(dq, (9, 30, 64, 4))                                 # hidden1 not a multiple of 16
     e.close(); u.close()
+
+
+def test_train_iters_one_graph_matches_oracle(dq):
+    """the reference's inner loop (q_agent.py:174-187) captured as ONE graph: 3 iterations of
+    (4 vector env steps + 1 update), replayed twice, vs the oracle stepping the same loop."""
+    import torch
+    dims = CFGS["cfg1"]
+    D = dims[0]
+    L_, n, B = 11, 64, 64
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=91, lr=1e-3)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, 512, 92, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    ct.add(cr.add(s, a, r, s2, d > 0)); e.replay_add(s, a, r, s2, d > 0)
+    P0 = rand_params(dims, 93)
+    e.set_params(P0); e.sync_target()
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 91, beta=0.4)
+    obs = np.random.default_rng(94).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
+    ctr = 0
+    for _ in range(6):
+        for _ in range(4):
+            ctr = lrn.actor_step(obs, 0.2, 0.05, ctr)
+        lrn.update(B)
+    with torch.cuda.stream(e.stream):
+        e.train_iters(3, 4, B); e.train_iters(3, 4, B)
+        e.stream.synchronize()
+    assert e.replay_size() == (cr.size, cr.rb.counter)
+    assert e.opt_count() == 6
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
+    assert np.array_equal(host(e.buffer(dq._lib.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
+    for x, y in zip((e.buffer(dq._lib.BUF_STATES).view(N, D), e.buffer(dq._lib.BUF_REWARDS)), (cr.arrays()[0], cr.arrays()[2])):
+        assert np.array_equal(host(x), y)
+    assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    e.close()
