@@ -46,6 +46,12 @@ class EngineConfig:
         return (self.obs_dim, self.hidden1, self.hidden2, self.num_actions)
 
 
+def default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("deep_q_learning_amd needs an MI355X (gfx950) GPU; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 class _DevView:
     """__cuda_array_interface__ holder so torch can alias handle-owned device memory."""
 
@@ -125,6 +131,17 @@ class Engine:
         return t.view(shape) if shape is not None else t
 
     # ------------------------------------------------------------- params / state
+    def load(self, params, which=L.BUF_PARAMS):
+        """upload a haiku-style tree (or flat tensor) unless it is the very tensor uploaded last"""
+        from ._tree import flatten
+        flat = params if isinstance(params, torch.Tensor) else flatten(params)
+        tag = (flat.data_ptr(), flat._version, which) if isinstance(flat, torch.Tensor) else None
+        cache = self.__dict__.setdefault("_loaded", {})
+        if cache.get(which) == tag and tag is not None:
+            return
+        self.set_params(flat, which)
+        cache[which] = tag
+
     def set_params(self, flat, which=L.BUF_PARAMS):
         if isinstance(flat, torch.Tensor) and flat.is_cuda:
             flat = self.dev(flat, torch.float32)

@@ -1,0 +1,208 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/dqn_hip.h declares, the
+host-side mirror behaves like the reference where that is checkable without a device, the oracle reproduces
+the committed golden vectors, and the N>1 data-parallel recipe is exercised with gloo at world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle as oc
+from _oracle import onp
+from test_oracle import CFGS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# --------------------------------------------------------------------------- C ABI
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dqn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dqn_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import deep_q_learning_amd as dq
+    lib = dq._lib.load()                                     # binds all of SIGNATURES / OTHER or raises
+    declared = header_functions()
+    assert len(declared) >= 35
+    bound = set(dq._lib.SIGNATURES) | set(dq._lib.OTHER)
+    assert set(declared) == bound, (set(declared) ^ bound)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dqn_abi_version() == 1
+    c = dq._lib.DqnConfig()
+    lib.dqn_default_config(C.byref(c))                       # Test/lunar_lander.py:23-48 defaults
+    assert (c.obs_dim, c.hidden1, c.hidden2, c.num_actions, c.capacity, c.max_batch) == (9, 32, 64, 4, 100000, 64)
+    assert abs(c.lr - 2e-4) < 1e-9 and abs(c.gamma - 0.99) < 1e-7 and c.optimizer == dq._lib.OPT_ADAMW
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dq._lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (dqn_[a-z_0-9]+)", out))
+    assert set(declared) <= exported
+
+
+def test_no_silent_fallback_without_gpu():
+    import deep_q_learning_amd as dq
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dq.Engine(dq.EngineConfig())
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deep-q-learning_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle_np|liboracle|dqn_oracle|import _oracle|from oracle", txt):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------ host-side mirror
+def test_param_tree_roundtrip_and_names():
+    from deep_q_learning_amd._tree import NAMES, dims_of, flatten, shapes, unflatten
+    dims = CFGS["cfg1"]
+    P = torch.tensor(onp.init_params(dims, 0))
+    tree = unflatten(P, dims)
+    assert list(tree) == list(NAMES) and tree["model/~/linear"]["w"].shape == (9, 32)      # haiku: w is [in,out]
+    assert tree["model/~/linear_2"]["w"].shape == (64, 1) and tree["model/~/linear_3"]["b"].shape == (4,)
+    assert flatten(tree) is P and dims_of(tree) == dims
+    plain = {k: dict(v) for k, v in tree.items()}
+    assert torch.equal(flatten(plain), P)
+    assert [s for _, _, s in shapes(dims)] == [s for _, _, s in onp.param_shapes(*dims)]
+
+
+def test_obs_wrapper_matches_reference_semantics():
+    """LunarLander/env.py:19-31"""
+    from deep_q_learning_amd.LunarLander.env import ObsWrapper
+
+    class Env:
+        def __init__(self): self.t = 0
+        def reset(self): self.t = 0; return np.arange(8, dtype=np.float64)
+        def step(self, a): self.t += 1; return np.full(8, self.t, np.float64), 1.5, self.t == 3, {}
+    w = ObsWrapper(Env(), 1500)
+    o = w.reset()
+    assert o.shape == (1, 9) and o.dtype == np.float32 and o[0, 8] == 0.0
+    o, r, d, _ = w.step(0)
+    assert o[0, 8] == np.float32(1 / 1500) and r == 1.5 and not d
+    assert np.array_equal(o, onp.obs_augment(np.full((1, 8), 1.0), np.array([1]), 1500))
+    w.step(0); w.reset()
+    assert w._step == 0
+
+
+def test_optimizer_state_shapes_like_optax():
+    from deep_q_learning_amd import optim
+    from deep_q_learning_amd._tree import unflatten
+    tree = unflatten(torch.zeros(onp.param_count(*CFGS["cfg1"])), CFGS["cfg1"])
+    st = optim.adamw(2e-4).init(tree)
+    assert len(st) == 3 and st[0].count == 0 and st[1] == optim.EmptyState() and optim.adamw(1e-3).weight_decay == 1e-4
+    assert len(optim.adam(1e-4).init(tree)) == 2 and optim.adam(1e-4).weight_decay == 0.0
+    assert st[0].mu["model/~/linear_1"]["w"].shape == (32, 64)
+
+
+def test_transform_finds_the_model():
+    from deep_q_learning_amd.LunarLander.dddqn import Model, transform, without_apply_rng
+    m = without_apply_rng(transform(lambda *args: Model(4)(*args)))     # Test/lunar_lander.py:47
+    assert m.dims(9) == (9, 32, 64, 4)
+    assert transform(lambda *a: Model(2, hidden=(64, 64))(*a)).dims(4) == (4, 64, 64, 2)
+
+
+# -------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("fn", sorted(f for f in os.listdir(GOLD) if f.startswith("cfg")))
+def test_oracles_reproduce_golden(fn):
+    z = np.load(os.path.join(GOLD, fn), allow_pickle=False)
+    dims = tuple(int(x) for x in z["dims"])
+    k = int(z["sub"])
+    full = onp.q_targets(z["P"], z["Pt"], z["s"], z["a"], z["r"], z["s2"], z["d"], 0.99, dims, np.float64, full=True)
+    for key in ("q", "next_q", "next_q_tm", "delta", "targets"):
+        assert np.array_equal(full[key], z[key]), key
+    assert np.array_equal(full["astar"], z["astar"])
+    g, L, dq = onp.grads(z["P"], z["s"], z["targets"].astype(np.float32), dims, None, np.float64)
+    assert L == z["loss"] and np.array_equal(g[::k], z["grads"]) and g.sum() == z["grads_sum"]
+    # the plain-C restatement (f32) against the same vectors, north_star tolerance
+    c = oc.q_targets(dims, z["P"], z["Pt"], z["s"], z["a"], z["r"], z["s2"], z["d"], 0.99)
+    assert np.array_equal(c["astar"], z["astar"])
+    assert np.allclose(c["targets"], z["targets"], rtol=1e-5, atol=1e-4)
+    gc, Lc, _ = oc.grads(dims, z["P"], z["s"], z["targets"].astype(np.float32))
+    assert abs(Lc - z["loss"]) <= 1e-5 * max(1, abs(z["loss"]))
+    assert np.max(np.abs(gc[::k] - z["grads"])) <= 2e-5 * max(np.abs(z["grads"]).max(), 1e-3)
+
+
+@pytest.mark.parametrize("fn", ["per_L12.npz", "per_L16.npz"])
+def test_sumtree_reproduces_golden(fn):
+    z = np.load(os.path.join(GOLD, fn), allow_pickle=False)
+    L, n, B, seed = int(z["L"]), int(z["n_add"]), int(z["B"]), int(z["seed"])
+    ct = oc.CPer(L)
+    ct.add(np.arange(n, dtype=np.int32)); ct.set(np.arange(n, dtype=np.int32), z["prio"])
+    for it in range(3):
+        idx, isw = ct.sample(n, B, 0.4 + 0.2 * it, seed, it)
+        assert np.array_equal(idx, z[f"idx_{it}"])
+        assert np.array_equal(isw.view(np.uint32), z[f"isw_{it}"].view(np.uint32))
+        ct.update(idx, z[f"td_{it}"])
+        assert ct.tree[1] == z[f"total_{it}"] and ct.pmax == z[f"pmax_{it}"]
+    assert np.array_equal(ct.tree[:64], z["tree_top"])
+
+
+# --------------------------------------------------------- N > 1 recipe on gloo, 2 ranks
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    from deep_q_learning_amd import dist as dd
+    r, w, _ = dd.init_from_env("gloo")
+    dims = CFGS["cfg1"]
+    P = torch.tensor(onp.init_params(dims, 0 if r == 0 else 99))
+    dd.broadcast_params(P)                                        # replicas start identical
+    P = P.numpy().copy()
+    from test_oracle import make_batch
+    mu, nu, cnt = np.zeros(P.size), np.zeros(P.size), 0
+    Pw = P.astype(np.float64)
+    for it in range(3):                                           # own minibatch per rank, one all-reduce per update
+        s, a, rr, s2, d = make_batch(dims, 64, 1000 + 10 * it + r)
+        rr = np.clip(rr, -3, 3)
+        tg = onp.q_targets(Pw, P, s, a, rr, s2, d, 0.99, dims, np.float64)
+        g, _, _ = onp.grads(Pw, s, tg, dims, None, np.float64)
+        gt = torch.tensor(g)
+        dd.allreduce_grads(gt)                                    # SUM; the optimizer divides by world
+        Pw, mu, nu, cnt = onp.adam_step(Pw, gt.numpy(), mu, nu, cnt, 2e-4, dtype=np.float64, grad_scale=1.0 / w)
+    t = dd.max_over_ranks(float(r + 1))
+    q.put((r, Pw, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_recipe_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])                   # replicas stay bit-identical
+    assert res[0][2] == res[1][2] == 2.0                          # max-over-ranks timing helper
+    # equals one process applying the mean of the two per-rank gradients
+    dims = CFGS["cfg1"]
+    from test_oracle import make_batch
+    P0 = onp.init_params(dims, 0)
+    Pw, mu, nu, cnt = P0.astype(np.float64), np.zeros(P0.size), np.zeros(P0.size), 0
+    for it in range(3):
+        gs = []
+        for r in range(2):
+            s, a, rr, s2, d = make_batch(dims, 64, 1000 + 10 * it + r)
+            rr = np.clip(rr, -3, 3)
+            tg = onp.q_targets(Pw, P0, s, a, rr, s2, d, 0.99, dims, np.float64)
+            gs.append(onp.grads(Pw, s, tg, dims, None, np.float64)[0])
+        Pw, mu, nu, cnt = onp.adam_step(Pw, gs[0] + gs[1], mu, nu, cnt, 2e-4, dtype=np.float64, grad_scale=0.5)
+    assert np.allclose(res[0][1], Pw, rtol=0, atol=1e-12)
