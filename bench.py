@@ -58,7 +58,9 @@ def algorithmic_cost(name, L, n_params):
         return "mfma", F * N_ENVS
     if name == "td_bwd_rows":
         return "mfma", (2 * (1 + A) * H2 + 2 * H1 * H2) * B
-    if name in ("dw", "dw_adam"):
+    if name == "per_top":
+        return "hbm", 2 * 4 * 1024
+    if name in ("dw", "dw_adam", "dw_adam_perwrite"):
         return "mfma", 2 * B * (D * H1 + H1 * H2 + H2 * (1 + A))
     return "hbm", 0
 

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -83,7 +84,6 @@ struct dqn_handle {
     std::vector<const char *> ev_names;
     std::map<int, GraphSet> graphs;
     std::map<std::vector<int>, hipGraphExec_t> loop_graphs;      // (iters, env_steps, n_envs, B) -> graph
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // parallel graph branch
     void *comm = nullptr; int rank = 0, world = 1;
     std::map<int, std::pair<void *, int64_t>> bufs;
 };
@@ -165,11 +165,6 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     s0.b1pow = 1.0; s0.b2pow = 1.0; s0.pmax = 1.0f; s0.beta = cfg->per_beta; s0.lr = cfg->lr;
     e = hipMemcpy(h->st, &s0, sizeof(s0), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "state init: %s", hipGetErrorString(e)); }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipFree(h->arena); delete h; return fail(DQN_ERR_HIP, "stream/event creation failed");
-    }
     *out = h;
     return DQN_OK;
 }
@@ -192,9 +187,6 @@ extern "C" int dqn_destroy(dqn_handle *h) {
     destroy_graphs(h);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto e : h->events) (void)hipEventDestroy(e);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->arena) (void)hipFree(h->arena);
     delete h;
     return DQN_OK;
@@ -460,7 +452,7 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
 // sample -> three forwards -> TD / row backward -> weight gradients.
 // fuse_adam: optimizer applied in the dW epilogue (single GPU). fork: run the PER write-back on a
 // parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
-static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fork = false) {
+static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fuse_pw = false) {
     // q_agent.py:147-153 sample_batch
     if (h->cfg.use_per)
         launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
@@ -485,16 +477,13 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
     launch_bwd_rows(st, h->m, g, B, h->st);
     mark(h, st, "td_bwd_rows");
-    if (fork && h->cfg.use_per) {
-        (void)hipEventRecord(h->ev_fork, st);
-        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-        enqueue_per_writeback(h, B, h->side);
-        (void)hipEventRecord(h->ev_join, h->side);
-    }
+    PwArgs pw{};
+    if (fuse_pw && h->cfg.use_per)
+        pw = PwArgs{h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, h->cfg.per_alpha, h->cfg.per_eps};
     launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
-              h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{});
-    mark(h, st, fuse_adam ? "dw_adam" : "dw");
-    if (fork && h->cfg.use_per) (void)hipStreamWaitEvent(st, h->ev_join, 0);
+              h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{}, pw);
+    mark(h, st, fuse_adam ? (pw.tree ? "dw_adam_perwrite" : "dw_adam") : "dw");
+    if (pw.tree) { launch_per_top(st, h->st, h->tree, h->L); mark(h, st, "per_top"); }
 }
 
 static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
@@ -503,12 +492,13 @@ static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
     if (h->cfg.use_per) enqueue_per_writeback(h, B, st);
 }
 
-// the whole Agent._step; single GPU: optimizer fused into dW, PER write-back on a parallel branch
+// the whole Agent._step. Single GPU: optimizer fused into the dW epilogue, and the PER write-back waves
+// ride in the same launch as surplus workgroups (a forked graph branch measured slower: cross-queue
+// dependencies cost more than they hide).
 static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing) {
+    (void)capturing;
     if (h->world == 1) {
-        const bool fork = capturing && !h->profiling;
-        enqueue_backward(h, B, st, true, fork);
-        if (!fork && h->cfg.use_per) enqueue_per_writeback(h, B, st);
+        enqueue_backward(h, B, st, true, true);
     } else {
         enqueue_backward(h, B, st);
         enqueue_apply(h, B, st);

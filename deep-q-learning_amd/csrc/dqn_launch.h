@@ -46,6 +46,9 @@ struct BwdArgs {
     float *loss_part;                  // [ceil(B/16)]
 };
 
+struct PwArgs {             // sorted PER write-back run by surplus workgroups of k_dw when tree != NULL
+    float *tree; long long N; int L; const int32_t *idx; const float *td_abs; int B; float alpha, eps;
+};
 struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU fused path) when P != NULL
     float *P, *mu, *nu, *pack; int adamw; float b1, b2, eps, wd, grad_scale;
 };
@@ -60,7 +63,9 @@ void launch_loss(hipStream_t s, const float *pred, const float *targets, const f
 void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
-               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam);
+               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam,
+               const PwArgs &pw = PwArgs{});
+void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L);
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
 void launch_env_step(hipStream_t s, DqnState *st, float *states, int32_t *actions, float *rewards,

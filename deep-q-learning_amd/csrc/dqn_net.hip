@@ -16,6 +16,7 @@
 // :52-61 (targets), :35-36 (loss), :23-25 (grad + optimizer).
 #include "dqn_device.h"
 #include "dqn_launch.h"
+#include "dqn_per_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -671,10 +672,18 @@ __device__ __forceinline__ void scatter_packs(const NetDims &m, int i, float v, 
 __global__ void __launch_bounds__(256)
 k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, const float *__restrict__ ph2,
      const float *__restrict__ pdz1, const float *__restrict__ pdz2, const float *__restrict__ pdz3, int B,
-     float *grad, const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, AdamArgs ad) {
+     float *grad, const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, AdamArgs ad, PwArgs pw,
+     int tiles) {
     __shared__ float red[4][64][4];
     __shared__ float redb[4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if ((int)blockIdx.x >= tiles) {
+        // surplus workgroups: the PER priority write-back of this batch (independent of the weight
+        // gradients; sharing the launch hides it behind the dW tiles on other CUs)
+        if (wave == 0)
+            per_write_sorted_wave(st, pw.tree, pw.N, pw.L, pw.idx, pw.td_abs, pw.B, 1, pw.alpha, pw.eps, (int)blockIdx.x - tiles);
+        return;
+    }
     const int KQb = (B + 15) / 16;
     const int MT2 = m.H1 / 16, NT2 = m.H2 / 16, MT1 = m.KQ1, NT1 = m.H1 / 16, MTH = m.H2 / 16;
     int b = blockIdx.x;
@@ -798,7 +807,7 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
         __syncthreads();
         if (tid == 0) {
             const unsigned int ticket = atomicAdd(&st->arrive, 1u);
-            if (ticket == gridDim.x - 1) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
+            if (ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
         }
     }
     STAMP(6, 3);
@@ -806,10 +815,12 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
 
 void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
-               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam) {
+               const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam,
+               const PwArgs &pw) {
     const int tiles = (m.H1 / 16) * (m.H2 / 16) + m.KQ1 * (m.H1 / 16) + m.H2 / 16;
-    hipLaunchKernelGGL(k_dw, dim3(tiles), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, B, grad,
-                       loss_part, loss_out, st, bump_ctr, adam);
+    const int extra = pw.tree ? (pw.B + 63) / 64 : 0;
+    hipLaunchKernelGGL(k_dw, dim3(tiles + extra), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, B, grad,
+                       loss_part, loss_out, st, bump_ctr, adam, pw, tiles);
 }
 
 // ---------------------------------------------------------------------------- optimizer

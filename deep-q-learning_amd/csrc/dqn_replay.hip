@@ -9,6 +9,7 @@
 // reference; SURVEY.md 8(c2) is its specification.
 #include "dqn_device.h"
 #include "dqn_launch.h"
+#include "dqn_per_device.h"
 
 
 // ------------------------------------------------------------------ ring insert
@@ -262,8 +263,6 @@ k_per_write(DqnState *st, float *tree, unsigned long long *stamp, long long N, i
 //     depth-TOP values and re-reduced level by level (recomputing an untouched parent from unchanged
 //     children reproduces its value bit for bit).
 // Only LDS barriers inside the loops. One workgroup, IPT items per thread held in registers.
-#define PW_TOP 10
-#define PW_BOT 21            // bottom levels handled by the hash phase: L - PW_TOP <= 21 (L <= 31)
 __device__ __forceinline__ unsigned pw_hash(unsigned key, unsigned mask) { return (key * 2654435761u) >> 7 & mask; }
 
 template <int IPT>
@@ -429,107 +428,10 @@ k_per_write_lds(DqnState *st, float *tree, long long N, int L, const int32_t *__
 //                       once, parents go to HBM unawaited. Longer runs take a wave-serial slow path.
 //   k_per_top           one workgroup reloads depth TOP (contiguous) and re-reduces the top image in LDS.
 // Scattered traffic is thereby spread over B/64 CUs instead of one. Same arithmetic as k_per_write.
-__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
-
 __global__ void __launch_bounds__(64)
 k_per_write_sorted(DqnState *st, float *tree, long long N, int L, const int32_t *__restrict__ idx,
                    const float *__restrict__ val, int B, int mode, float alpha, float eps) {
-    const int lane = threadIdx.x, base = blockIdx.x * 64;
-    const int TOP = L < PW_TOP ? L : PW_TOP, SH = L - TOP;       // depth-TOP subtree id = leaf >> SH
-    STAMP(4, 0);
-    // ---- which items does this wave own?
-    const int i0 = base + lane;
-    const int my = i0 < B ? idx[i0] : -1;
-    const int prev = (i0 > 0 && i0 <= B) ? idx[i0 - 1] : -1;
-    const bool starts = i0 < B && (i0 == 0 || (my >> SH) != (prev >> SH));
-    const unsigned long long sm = __ballot(starts);
-    if (sm == 0ull) return;                                       // every item here belongs to an earlier owner
-    const int first = base + __ffsll((long long)sm) - 1;
-    const int last_chunk = (base + 63 < B - 1) ? base + 63 : B - 1;
-    const int s_last = shfl_i(my, last_chunk - base) >> SH;
-    // extension past the chunk end: following items that still belong to subtree s_last
-    int ext = 0;
-    {
-        int pos = base + 64;
-        for (;;) {
-            const int j = pos + lane;
-            const bool same = j < B && (idx[j] >> SH) == s_last;
-            const unsigned long long mm = __ballot(same);
-            if (mm == ~0ull) { ext += 64; pos += 64; continue; }
-            ext += __ffsll((long long)~mm) - 1;
-            break;
-        }
-    }
-    const int total = (last_chunk + 1 - first) + ext;
-    float lmax = 0.0f;
-    STAMP(4, 1);
-
-    if (total <= 64) {
-        // ---- fast path: one item per lane, registers only
-        const int i = first + lane;
-        bool live = lane < total;
-        long long x = live ? N + (long long)idx[i] : 0;
-        float v = 0.0f;
-        if (live) { v = (mode == 0) ? val[i] : pow_det(val[i] + eps, alpha); lmax = v; }
-        float sib[PW_BOT];
-#pragma unroll
-        for (int l = 0; l < PW_BOT; ++l) sib[l] = (live && l < SH) ? tree[(x >> l) ^ 1] : 0.0f;
-        {   // equal leaves: the highest batch position (last of the run) wins
-            const long long xn = __shfl_down(x, 1, 64);
-            if (live && lane + 1 < total && xn == x) live = false;
-        }
-        if (live) tree[x] = v;
-        STAMP(4, 2);
-#pragma unroll
-        for (int l = 0; l < PW_BOT; ++l) {
-            if (l >= SH) break;
-            const unsigned long long m = __ballot(live);
-            const unsigned long long mr = (lane == 63) ? 0ull : (m & ~((2ull << lane) - 1ull));
-            const unsigned long long ml = m & ((1ull << lane) - 1ull);
-            const int r = mr ? __ffsll((long long)mr) - 1 : lane;
-            const int lf = ml ? 63 - __clzll((long long)ml) : lane;
-            const long long xr = __shfl(x, r, 64), xl = __shfl(x, lf, 64);
-            const float vr = shfl_f(v, r), vl = shfl_f(v, lf);
-            (void)vl;
-            if (live) {
-                if ((x & 1) == 0) {
-                    const bool has = mr && xr == x + 1;
-                    v = v + (has ? vr : sib[l]);
-                    x >>= 1;
-                    tree[x] = v;
-                } else {
-                    const bool has = ml && xl == x - 1;
-                    if (has) live = false;                        // the left sibling carries the pair upward
-                    else { v = sib[l] + v; x >>= 1; tree[x] = v; }
-                }
-            }
-        }
-    } else {
-        // ---- slow path (a depth-TOP subtree holds > 64 sampled items): wave-serial, level-synchronous
-        // through L2 (agent-scope accesses bypass this CU's L1 between levels)
-        for (int j = first + lane; j < first + total; j += 64) {
-            const float p = (mode == 0) ? val[j] : pow_det(val[j] + eps, alpha);
-            lmax = fmaxf(lmax, p);
-            const bool loser = (j + 1 < first + total) && idx[j + 1] == idx[j];
-            if (!loser) __hip_atomic_store(&tree[N + idx[j]], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (int lvl = 1; lvl <= SH; ++lvl) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int j = first + lane; j < first + total; j += 64) {
-                const long long node = (N + (long long)idx[j]) >> lvl;
-                const float a = __hip_atomic_load(&tree[2 * node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float b = __hip_atomic_load(&tree[2 * node + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&tree[node], a + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    STAMP(4, 3);
-    // running max priority: order-independent (positive floats order like their bit patterns)
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(&st->pmax), __float_as_uint(lmax));
-    STAMP(4, 4);
+    per_write_sorted_wave(st, tree, N, L, idx, val, B, mode, alpha, eps, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -816,6 +718,12 @@ void launch_env_step(hipStream_t st_, DqnState *st, float *states, int32_t *acti
     const size_t lds = (tree && n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(n + 2) + 64) : 0;
     hipLaunchKernelGGL(k_env_step, dim3(1), dim3(pow2_threads(n * (D + 1), 64, 1024)), lds, st_, st, states, actions, rewards,
                        observations, dones, N, D, tree, Ntree, L, env_obs, env_a, n, seed, p_done);
+}
+
+void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
+    const int TOP = L < PW_TOP ? L : PW_TOP;
+    const int n = 1 << TOP;
+    hipLaunchKernelGGL(k_per_top, dim3(1), dim3(n < 1024 ? (n < 64 ? 64 : n) : 1024), sizeof(float) * 2 * n, st_, st, tree, L);
 }
 
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
