@@ -65,6 +65,28 @@ def algorithmic_cost(name, L, n_params):
     return "hbm", 0
 
 
+PMC_KEYS = {   # bench kernel label -> (key in profiles/*_pmc.json, FETCH_SIZE correction)
+    # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads; other widths
+    # are uncalibrated and taken as reported.
+    "act_fwd_policy": ("k_qnet_fwd<4, 4>/grid4096", 2.0), "qnet_fwd_x3": ("k_qnet_fwd<4, 4>/grid49152", 2.0),
+    "td_bwd_rows": ("k_bwd_rows<4, 4>", 2.0), "dw_adam_perwrite": ("k_dw", 2.0), "dw_adam": ("k_dw", 2.0), "dw": ("k_dw", 2.0),
+    "per_sample": ("k_per_sample", 1.0), "env_step_add": ("k_env_step", 1.0), "per_top": ("k_per_top", 1.0),
+}
+
+
+def pmc_traffic(label):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files or label not in PMC_KEYS:
+        return None
+    key, corr = PMC_KEYS[label]
+    rec = json.load(open(files[-1])).get(key)
+    if not rec or "FETCH_SIZE_KB_per_launch_median" not in rec or "WRITE_SIZE_KB_per_launch_median" not in rec:
+        return None
+    return (rec["FETCH_SIZE_KB_per_launch_median"] * corr + rec["WRITE_SIZE_KB_per_launch_median"]) * 1024.0
+
+
 def prefill(eng, gen):
     """ring full (2^20 transitions) with SURVEY.md 8(d)'s synthetic distribution, priorities U(0,1)^0.6"""
     N = 1 << LOG2N
@@ -239,12 +261,13 @@ def main():
             avg_ms = float(np.median(v))
             ach = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12) if avg_ms > 0 else 0.0
             peak = HBM_PEAK_GBS if bound == "hbm" else MFMA_F32_PEAK_TFLOPS
-            per_step[name] = {"bound": bound, "avg_us": avg_ms * 1e3, "launches_per_step": launches,
+            per_step[name] = {"bound": bound, "avg_us": avg_ms * 1e3, "launches_per_step": launches, "traffic": pmc_traffic(name),
                               "achieved": ach, "peak": peak, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
                               "frac": ach / peak}
         dom = max(per_step, key=lambda k: per_step[k]["avg_us"] * per_step[k]["launches_per_step"])
         roof = {k: per_step[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-        roof.update({"kernel": dom, "avg_us": per_step[dom]["avg_us"], "traffic": None,
+        roof.update({"kernel": dom, "avg_us": per_step[dom]["avg_us"], "traffic": pmc_traffic(dom),
+                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r*_pmc.json, bytes per launch",
                      "launches_per_step": per_step[dom]["launches_per_step"],
                      "timing": "HIP events around each eager launch on the launch stream, median of "
                                f"{args.profile_steps} (event overhead included); rocprofv3 summary in profiles/"})
