@@ -61,9 +61,10 @@ struct dqn_handle {
     NetDims m;
     int L = 0;                 // tree levels (N_tree = 2^L >= capacity)
     long long Ntree = 0;
-    int Bp = 0;                // max_batch rounded up to 16
+    int Bp = 0;                // max_batch rounded up to 16 (f32) / 32 (bf16)
+    bool bf16 = false;         // DQN_PREC_BF16: packs and stashes hold bf16 data
     void *arena = nullptr;
-    size_t arena_bytes = 0;
+    size_t arena_bytes = 0, pack_bytes = 0;
     DqnState *st = nullptr;
     float *params = nullptr, *target = nullptr, *mu = nullptr, *nu = nullptr, *grad = nullptr;
     float *pack = nullptr, *pack_t = nullptr;
@@ -92,6 +93,21 @@ static Rccl g_rccl;
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// precision dispatch
+static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pack) {
+    if (h->bf16) launch_pack_bf16(s, h->m, params, pack); else launch_pack(s, h->m, params, pack);
+}
+static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B) {
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B); else launch_qnet_fwd(s, h->m, p, n, B);
+}
+static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
+    if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
+}
+static void L_dw(dqn_handle *h, hipStream_t s, int B, float *loss_out, int bump, const AdamArgs &ad, const PwArgs &pw) {
+    if (h->bf16) launch_dw_bf16(s, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part, loss_out, h->st, bump, ad, pw);
+    else launch_dw(s, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part, loss_out, h->st, bump, ad, pw);
+}
+
 // record an event after the launch just enqueued (profiling mode only)
 static void mark(dqn_handle *h, hipStream_t st, const char *name) {
     if (!h->profiling) return;
@@ -109,7 +125,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(A >= 1 && A <= 15, "num_actions %d out of range [1,15]", A);
     REQUIRE(cfg->capacity >= 1 && cfg->capacity <= (1ll << 30), "capacity out of range");
     REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= (1 << 22), "max_batch out of range");
-    REQUIRE(cfg->precision == DQN_PREC_F32, "precision %d not built (f32 only in this build)", cfg->precision);
+    REQUIRE(cfg->precision == DQN_PREC_F32 || cfg->precision == DQN_PREC_BF16, "unknown precision %d", cfg->precision);
     REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
     REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
 
@@ -118,7 +134,8 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->cfg = *cfg;
     h->m = make_dims(D, H1, H2, A);
     h->world = cfg->world_size;
-    h->Bp = (cfg->max_batch + 15) / 16 * 16;
+    h->bf16 = cfg->precision == DQN_PREC_BF16;
+    h->Bp = h->bf16 ? (cfg->max_batch + 31) / 32 * 32 : (cfg->max_batch + 15) / 16 * 16;
     if (cfg->use_per) {
         int L = 0; while ((1ll << L) < cfg->capacity) ++L;
         if (L < 1) L = 1;
@@ -134,7 +151,10 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->st, sizeof(DqnState));
     add(&h->params, P * 4, DQN_BUF_PARAMS); add(&h->target, P * 4, DQN_BUF_TARGET);
     add(&h->mu, P * 4, DQN_BUF_MU); add(&h->nu, P * 4, DQN_BUF_NU); add(&h->grad, P * 4, DQN_BUF_GRAD);
-    add(&h->pack, h->m.pack_floats * 4); add(&h->pack_t, h->m.pack_floats * 4);
+    const size_t esz = h->bf16 ? 2 : 4;                           // element size of packs and stashes
+    const size_t pack_bytes = h->bf16 ? (size_t)bf16_pack_elems(h->m) * 2 : (size_t)h->m.pack_floats * 4;
+    h->pack_bytes = pack_bytes;
+    add(&h->pack, pack_bytes); add(&h->pack_t, pack_bytes);
     add(&h->states, N * D * 4, DQN_BUF_STATES); add(&h->observations, N * D * 4, DQN_BUF_OBSERVATIONS);
     add(&h->rewards, N * 4, DQN_BUF_REWARDS); add(&h->actions, N * 4, DQN_BUF_ACTIONS);
     add(&h->dones, N, DQN_BUF_DONES);
@@ -143,8 +163,8 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->bisw, Bp * 4, DQN_BUF_BATCH_ISW); add(&h->btd, Bp * 4, DQN_BUF_BATCH_TD); add(&h->btd_abs, Bp * 4);
     add(&h->bdf, Bp * 4); add(&h->ba, Bp * 4); add(&h->bidx, Bp * 4, DQN_BUF_BATCH_IDX); add(&h->bd, Bp);
     add(&h->q, Bp * A * 4); add(&h->nq, Bp * A * 4); add(&h->nt, Bp * A * 4);
-    add(&h->px, Bp * K1 * 4); add(&h->ph1, Bp * H1 * 4); add(&h->ph2, Bp * H2 * 4);
-    add(&h->pdz1, Bp * H1 * 4); add(&h->pdz2, Bp * H2 * 4); add(&h->pdz3, Bp * 16 * 4);
+    add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
+    add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
     add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp);
@@ -212,8 +232,8 @@ extern "C" int dqn_set_params(dqn_handle *h, int which, const float *src, int sr
     REQUIRE(dst, "dqn_set_params: bad selector %d", which);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(dst, src, h->m.P * 4, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
-    if (which == DQN_BUF_PARAMS) launch_pack(s, h->m, h->params, h->pack);
-    if (which == DQN_BUF_TARGET) launch_pack(s, h->m, h->target, h->pack_t);
+    if (which == DQN_BUF_PARAMS) L_pack(h, s, h->params, h->pack);
+    if (which == DQN_BUF_TARGET) L_pack(h, s, h->target, h->pack_t);
     HIP_TRY(hipGetLastError());
     if (src_is_host) HIP_TRY(hipStreamSynchronize(s));      // the host buffer may be pageable / reused
     return DQN_OK;
@@ -355,7 +375,7 @@ extern "C" int dqn_qnet_forward(dqn_handle *h, int which_net, const float *x, in
     REQUIRE(which_net == DQN_NET_ONLINE || which_net == DQN_NET_TARGET, "bad net selector");
     REQUIRE(B >= 1, "B must be >= 1");
     FwdPass p = make_pass(h, which_net, x, q, feat, false);
-    launch_qnet_fwd((hipStream_t)stream, h->m, &p, 1, B);
+    L_fwd(h, (hipStream_t)stream, &p, 1, B);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -380,7 +400,7 @@ extern "C" int dqn_q_targets(dqn_handle *h, const float *s, const int32_t *a, co
     FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false),      // :52
                      make_pass(h, DQN_NET_ONLINE, s2, h->nq, nullptr, false),    // :53
                      make_pass(h, DQN_NET_TARGET, s2, h->nt, nullptr, false) };  // :54
-    launch_qnet_fwd(st, h->m, p, 3, B);
+    L_fwd(h, st, p, 3, B);
     launch_td(st, h->q, h->nq, h->nt, a, r, d, nullptr, h->cfg.gamma, B, h->cfg.num_actions, targets,
               nullptr, nullptr, nullptr, h->scratch);
     HIP_TRY(hipGetLastError());
@@ -393,7 +413,7 @@ extern "C" int dqn_loss(dqn_handle *h, const float *s, const float *targets, con
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
     FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, false);
-    launch_qnet_fwd(st, h->m, &p, 1, B);
+    L_fwd(h, st, &p, 1, B);
     launch_loss(st, h->q, targets, isw, B, h->cfg.num_actions, loss);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
@@ -405,20 +425,19 @@ extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, co
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
     FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, true);
-    launch_qnet_fwd(st, h->m, &p, 1, B);
+    L_fwd(h, st, &p, 1, B);
     BwdArgs g{};
     g.q = h->q; g.targets = targets; g.isw = isw; g.gamma = h->cfg.gamma;
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3; g.loss_part = h->loss_part;
-    launch_bwd_rows(st, h->m, g, B, h->st);
-    launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
-              loss ? loss : h->loss_dev, h->st, 0, AdamArgs{});
+    L_bwd(h, st, g, B);
+    L_dw(h, st, B, loss ? loss : h->loss_dev, 0, AdamArgs{}, PwArgs{});
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
 
 static void enqueue_adam(dqn_handle *h, hipStream_t st) {
-    launch_adam(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack,
+    (h->bf16 ? launch_adam_bf16 : launch_adam)(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack,
                 h->cfg.optimizer == DQN_OPT_ADAMW, h->cfg.b1, h->cfg.b2, h->cfg.eps, h->cfg.weight_decay,
                 1.0f / (float)h->world);
 }
@@ -466,7 +485,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, true),
                      make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),
                      make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false) };
-    launch_qnet_fwd(st, h->m, p, 3, B);
+    L_fwd(h, st, p, 3, B);
     mark(h, st, "qnet_fwd_x3");
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
     BwdArgs g{};
@@ -475,13 +494,12 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
-    launch_bwd_rows(st, h->m, g, B, h->st);
+    L_bwd(h, st, g, B);
     mark(h, st, "td_bwd_rows");
     PwArgs pw{};
     if (fuse_pw && h->cfg.use_per)
         pw = PwArgs{h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, h->cfg.per_alpha, h->cfg.per_eps};
-    launch_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part,
-              h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{}, pw);
+    L_dw(h, st, B, h->loss_dev, 1, fuse_adam ? adam_args(h) : AdamArgs{}, pw);
     mark(h, st, fuse_adam ? (pw.tree ? "dw_adam_perwrite" : "dw_adam") : "dw");
     if (pw.tree) { launch_per_top(st, h->st, h->tree, h->L); mark(h, st, "per_top"); }
 }
@@ -509,7 +527,7 @@ static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing)
 static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st) {
     FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);       // :176 _policy(state)
     p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
-    launch_qnet_fwd(st, h->m, &p, 1, n_envs);
+    L_fwd(h, st, &p, 1, n_envs);
     mark(h, st, "act_fwd_policy");
     launch_env_step(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones, h->cfg.capacity,
                     h->cfg.obs_dim, h->cfg.use_per ? h->tree : nullptr, h->Ntree, h->L, h->env_obs, h->env_a,
@@ -565,7 +583,7 @@ extern "C" int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, 
     hipStream_t st = (hipStream_t)stream;
     FwdPass p = make_pass(h, DQN_NET_ONLINE, s, nullptr, nullptr, false);
     p.act_out = actions; p.act_state = nullptr; p.act_eps = epsilon; p.act_seed = seed; p.act_ctr = ctr;
-    launch_qnet_fwd(st, h->m, &p, 1, n);
+    L_fwd(h, st, &p, 1, n);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -618,7 +636,7 @@ extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {
     REQUIRE(h, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->target, h->params, h->m.P * 4, hipMemcpyDeviceToDevice, st));   // q_agent.py:144
-    HIP_TRY(hipMemcpyAsync(h->pack_t, h->pack, h->m.pack_floats * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->pack_t, h->pack, h->pack_bytes, hipMemcpyDeviceToDevice, st));
     return DQN_OK;
 }
 

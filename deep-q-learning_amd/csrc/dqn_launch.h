@@ -99,3 +99,15 @@ void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
                       int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,
                       long long ring_capacity);
+
+// ----- bf16 MFMA variants (dqn_net_bf16.hip); pointer fields typed float* carry bf16 data -------------
+long long bf16_pack_elems(const NetDims &m);
+void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B);
+void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
+void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
+                    const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,
+                    const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam,
+                    const PwArgs &pw);
+void launch_adam_bf16(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
+                      float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);

@@ -1,0 +1,134 @@
+"""GPU tests (-m gpu) of the bf16 MFMA precision mode (dqn_config.precision = DQN_PREC_BF16): bf16 operands,
+f32 accumulation, f32 master weights. This is the throughput path; its tolerance is bf16's (2^-8 per operand),
+stated per assert -- the 1e-5 parity bar belongs to the f32 path (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+import _oracle as oc
+from _oracle import onp
+from test_oracle import CFGS, make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dq(torch_cuda):
+    import deep_q_learning_amd as pkg
+    return pkg
+
+
+def mk(dq, dims, **kw):
+    return dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3],
+                                     precision="bf16", **kw))
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_params(dims, seed):
+    P = onp.init_params(dims, seed)
+    return (P + 0.05 * np.random.default_rng(seed + 100).standard_normal(P.size)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg1", 37), ("cfg2", 1024), ("cfg3", 2048), ("cfg2", 100)])
+def test_bf16_forward_and_targets(dq, name, B):
+    dims = CFGS[name]
+    e = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 0), rand_params(dims, 1)
+    e.set_params(P); e.set_params(Pt, dq._lib.BUF_TARGET)
+    s, a, r, s2, d = make_batch(dims, B, 2)
+    r = np.clip(r, -3, 3)
+    q = host(e.forward(s))
+    q64 = onp.forward(P, s, dims, np.float64)
+    scale = np.abs(q64).max()
+    assert np.max(np.abs(q - q64)) <= 2e-2 * scale, np.max(np.abs(q - q64)) / scale      # bf16: ~2^-8 per operand
+    assert np.array_equal(q, host(e.forward(s)))                                          # deterministic
+    t = host(e.q_targets(s, a, r, s2, d))
+    full = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64, full=True)
+    t64 = full["targets"]
+    top2 = np.sort(full["next_q"], axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 4e-2 * scale             # rows whose double-Q argmax bf16 cannot flip
+    assert clear.mean() > 0.5
+    assert np.max(np.abs(t - t64)[clear]) <= 3e-2 * max(np.abs(t64).max(), 1.0)
+    assert np.array_equal(e.get_params(host=True), P)                                     # master weights stay f32
+    e.close()
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 2048), ("cfg1", 50)])
+def test_bf16_grads(dq, name, B):
+    dims = CFGS[name]
+    e = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 3), rand_params(dims, 4)
+    e.set_params(P)
+    s, a, r, s2, d = make_batch(dims, B, 5)
+    r = np.clip(r, -3, 3)
+    targets = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64).astype(np.float32)
+    isw = np.random.default_rng(6).uniform(0.2, 1, B).astype(np.float32)
+    g64, L64, _ = onp.grads(P, s, targets, dims, isw, np.float64)
+    g, L = e.grads(s, targets, isw)
+    g = host(g)
+    assert abs(host(L)[0] - L64) <= 3e-2 * max(1.0, abs(L64))
+    # cosine similarity and scale of the whole gradient; elementwise within 5 % of the largest entry
+    cos = float(g @ g64 / (np.linalg.norm(g) * np.linalg.norm(g64)))
+    assert cos > 0.999, cos
+    assert np.max(np.abs(g - g64)) <= 5e-2 * np.abs(g64).max()
+    g2, _ = e.grads(s, targets, isw)
+    assert np.array_equal(g, host(g2))                                                    # fixed reduction order
+    e.close()
+
+
+def test_bf16_training_reduces_loss_and_tracks_f32(dq):
+    """300 fused updates on a fixed PER replay: the bf16 learner learns, and stays close to the f32 learner"""
+    import torch
+    dims = CFGS["cfg1"]
+    B, L_ = 64, 10
+    N = 1 << L_
+    s, a, r, s2, d = make_batch(dims, N, 7, terminal_frac=0.05)
+    r = np.clip(r, -1, 1)
+    P0 = onp.init_params(dims, 8)
+    out = {}
+    for prec in ("bf16", "f32"):
+        e = dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=N,
+                                      use_per=True, max_batch=B, seed=9, lr=2e-3, precision=prec))
+        e.replay_add(s, a, r, s2, d > 0)
+        e.set_params(P0); e.sync_target()
+        losses = []
+        with torch.cuda.stream(e.stream):
+            for it in range(300):
+                e.update(B)
+                if it % 10 == 0:
+                    e.stream.synchronize(); losses.append(float(e.last_loss().item()))
+            e.stream.synchronize()
+        out[prec] = (np.array(losses), e.get_params(host=True), host(e.buffer(dq._lib.BUF_TREE)))
+        assert e.opt_count() == 300
+        e.close()
+    lb, pb, tb = out["bf16"]; lf, pf, tf = out["f32"]
+    assert np.isfinite(lb).all() and lb[-5:].mean() < 0.7 * lb[:3].mean()
+    assert abs(lb[-10:].mean() - lf[-10:].mean()) <= 0.5 * lf[-10:].mean() + 1e-3     # minibatch losses are noisy
+    k = np.arange(1, N)
+    assert np.array_equal(tb[k], tb[2 * k] + tb[2 * k + 1])                               # sum-tree invariant holds
+    db, df = pb - P0, pf - P0                                                             # same direction of travel
+    cos = float(db @ df / (np.linalg.norm(db) * np.linalg.norm(df)))
+    print("bf16 vs f32 after 300 updates: cos", cos, "norm ratio", np.linalg.norm(db) / np.linalg.norm(df))
+    assert cos > 0.8 and 0.7 < np.linalg.norm(db) / np.linalg.norm(df) < 1.4
+
+
+def test_bf16_actor_loop_runs(dq):
+    import torch
+    dims = CFGS["cfg2"]
+    e = mk(dq, dims, capacity=1 << 12, use_per=True, max_batch=1024, seed=3)
+    e.set_params(rand_params(dims, 10)); e.sync_target()
+    rng = np.random.default_rng(11)
+    e.replay_add(rng.standard_normal((2048, 8)), rng.integers(0, 4, 2048), rng.standard_normal(2048),
+                 rng.standard_normal((2048, 8)), rng.random(2048) < 0.05)
+    e.env_reset(rng.standard_normal((256, 8)).astype(np.float32), 0.01); e.set_epsilon(0.15)
+    with torch.cuda.stream(e.stream):
+        for _ in range(5):
+            e.train_iters(4, 4, 1024)
+        e.stream.synchronize()
+    assert e.opt_count() == 20 and e.replay_size()[1] == 2048 + 20 * 4 * 256
+    assert np.isfinite(e.get_params(host=True)).all() and np.isfinite(float(e.last_loss().item()))
+    acts = host(e.buffer(dq._lib.BUF_ENV_ACTIONS, torch.int32))[:256]
+    assert acts.min() >= 0 and acts.max() < 4
+    e.close()

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Batch sweep: per-kernel achieved GB/s / TFLOP/s against the roofline for B = 2^10 .. 2^max,
+to separate the latency floor (what bench.py's B=1024 sits on) from the bandwidth / MFMA slope.
+    python tools/sweep.py [--max-log2 17] [--json out.json]
+Timing: HIP events around `reps` back-to-back eager launches on one stream (launch gaps included)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import deep_q_learning_amd as dq  # noqa: E402
+
+D, H1, H2, A, L = bench.D, bench.H1, bench.H2, bench.A, bench.LOG2N
+F = 2 * (D * H1 + H1 * H2 + H2 * (1 + A))
+
+
+def timed(fn, reps, stream):
+    fn(); fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-log2", type=int, default=17)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    maxB = 1 << args.max_log2
+    eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << L, use_per=True,
+                                    max_batch=maxB, seed=3))
+    gen = torch.Generator(device=eng.device); gen.manual_seed(0)
+    eng.set_params(torch.randn(eng.param_count) * 0.05); eng.sync_target()
+    bench.prefill(eng, gen)
+    rows = []
+    with torch.cuda.stream(eng.stream):
+        st = eng.stream
+        for lb in range(10, args.max_log2 + 1):
+            B = 1 << lb
+            reps = max(3, min(200, (1 << 22) // B))
+            x = torch.randn(B, D, device=eng.device, generator=gen)
+            tg = torch.randn(B, A, device=eng.device, generator=gen)
+            batch, idx, isw = eng.per_sample(B, 0.4, seed=1, ctr=0)
+            td = torch.rand(B, device=eng.device, generator=gen)
+            r = {"B": B}
+            t = timed(lambda: eng.per_sample(B, 0.4, seed=1, ctr=1), reps, st)          # + k_isw_normalize
+            r["per_sample_us"] = t * 1e6; r["per_sample_GBs"] = (4 * L + 16 * D + 26) * B / t / 1e9
+            t = timed(lambda: eng.per_update_sorted(idx, td), reps, st)
+            r["per_update_sorted_us"] = t * 1e6; r["per_update_sorted_GBs"] = (8 * L + 12) * B / t / 1e9
+            t = timed(lambda: eng.forward(x), reps, st)
+            r["fwd_us"] = t * 1e6; r["fwd_TFs"] = F * B / t / 1e12
+            t = timed(lambda: eng.lib.dqn_grads(eng.h, x.data_ptr(), tg.data_ptr(), None, B, None, eng._s()), reps, st)
+            bk = F + 2 * (H1 * H2 + H2 * (1 + A))
+            r["grads_us"] = t * 1e6; r["grads_TFs"] = (F + bk) * B / t / 1e12          # 1 fwd + bwd
+            rows.append(r)
+            print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
+    out = {"config": {"D": D, "H1": H1, "H2": H2, "A": A, "log2N": L, "dtype": "f32"},
+           "peaks": {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3}, "rows": rows}
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
