@@ -55,7 +55,7 @@ def algorithmic_cost(name, L, n_params):
         return "hbm", ((4 * D + 5) + 2 * (8 * D + 9) + (8 * L + 4)) * N_ENVS
     if name == "qnet_fwd_x3":
         return "mfma", 3 * F * B
-    if name == "act_fwd_policy":
+    if name in ("act_fwd_policy", "actor_step"):      # forward + policy + env step + ring/tree insert, one launch
         return "mfma", F * N_ENVS
     if name == "td_bwd_rows":
         return "mfma", (2 * (1 + A) * H2 + 2 * H1 * H2) * B
@@ -69,7 +69,7 @@ def algorithmic_cost(name, L, n_params):
 PMC_KEYS = {   # bench kernel label -> (key in profiles/*_pmc.json, FETCH_SIZE correction)
     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads; other widths
     # are uncalibrated and taken as reported.
-    "act_fwd_policy": ("k_qnet_fwd<4, 4>/grid4096", 2.0), "qnet_fwd_x3": ("k_qnet_fwd<4, 4>/grid49152", 2.0),
+    "act_fwd_policy": ("k_qnet_fwd<4, 4>/grid4096", 2.0), "actor_step": ("k_qnet_fwd<4, 4>/grid4096", 2.0), "qnet_fwd_x3": ("k_qnet_fwd<4, 4>/grid49152", 2.0),
     "td_bwd_rows": ("k_bwd_rows<4, 4>", 2.0), "dw_adam_perwrite": ("k_dw", 2.0), "dw_adam": ("k_dw", 2.0), "dw": ("k_dw", 2.0),
     "per_sample": ("k_per_sample", 1.0), "env_step_add": ("k_env_step", 1.0), "per_top": ("k_per_top", 1.0),
 }
@@ -260,7 +260,7 @@ def main():
     if rank == 0:
         per_step = {}
         for name, v in kern.items():
-            launches = TRAIN_FREQ if name in ("act_fwd_policy", "env_step_add") else 1
+            launches = TRAIN_FREQ if name in ("act_fwd_policy", "env_step_add", "actor_step") else 1
             bound, units = algorithmic_cost(name, LOG2N, eng.param_count)
             avg_ms = float(np.median(v))
             ach = units / (avg_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12) if avg_ms > 0 else 0.0

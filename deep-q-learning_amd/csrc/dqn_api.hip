@@ -2,6 +2,7 @@
 // kernel sequencing, hipGraph capture of the fused update, RCCL gradient all-reduce.
 #include "../../include/dqn_hip.h"
 #include "dqn_launch.h"
+#include "dqn_per_device.h"
 
 #include <dlfcn.h>
 #include <cmath>
@@ -97,8 +98,8 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pack) {
     if (h->bf16) launch_pack_bf16(s, h->m, params, pack); else launch_pack(s, h->m, params, pack);
 }
-static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B); else launch_qnet_fwd(s, h->m, p, n, B);
+static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr) {
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env); else launch_qnet_fwd(s, h->m, p, n, B, env);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -525,14 +526,16 @@ static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing)
 
 // q_agent.py:176-183 for n_envs device-resident synthetic envs: two kernels
 static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st) {
-    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);       // :176 _policy(state)
+    // ONE launch: forward + epsilon-greedy policy (:176), then per workgroup the synthetic transition, ring insert
+    // and state = observation of its 16 envs (:177-183); a surplus workgroup inserts the new leaves into the tree.
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);
     p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
-    L_fwd(h, st, &p, 1, n_envs);
-    mark(h, st, "act_fwd_policy");
-    launch_env_step(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones, h->cfg.capacity,
-                    h->cfg.obs_dim, h->cfg.use_per ? h->tree : nullptr, h->Ntree, h->L, h->env_obs, h->env_a,
-                    n_envs, h->cfg.seed, h->p_done);                                        // :177-183
-    mark(h, st, "env_step_add");
+    EnvArgs e{};
+    e.st = h->st; e.states = h->states; e.actions = h->actions; e.rewards = h->rewards; e.observations = h->observations;
+    e.dones = h->dones; e.cap = h->cfg.capacity; e.tree = h->cfg.use_per ? h->tree : nullptr; e.Nt = h->Ntree; e.L = h->L;
+    e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
+    L_fwd(h, st, &p, 1, n_envs, &e);
+    mark(h, st, "actor_step");
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only)

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "dqn_device.h"
 
+struct EnvArgs;   // dqn_per_device.h
+
 // ----- network geometry -----------------------------------------------------------------
 // Flat parameter layout (haiku leaf order, w is [in,out] row-major; LunarLander/dddqn.py:19-22):
 //   w1[D*H1] b1[H1] w2[H1*H2] b2[H2] wv[H2] bv[1] wa[H2*A] ba[A]
@@ -54,7 +56,7 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 };
 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
-void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B);
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
                const float *r, const float *d, const float *isw, float gamma, int B, int A,
                float *targets, float *td, float *dq, float *loss, float *scratch);
@@ -68,9 +70,7 @@ void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L);
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
-void launch_env_step(hipStream_t s, DqnState *st, float *states, int32_t *actions, float *rewards,
-                     float *observations, uint8_t *dones, long long N, int D, float *tree, long long Ntree, int L,
-                     float *env_obs, const int32_t *env_a, int n, unsigned long long seed, float p_done);
+void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *env_a);
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
                    unsigned long long ctr, int32_t *actions, const DqnState *st_from);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
@@ -103,7 +103,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 // ----- bf16 MFMA variants (dqn_net_bf16.hip); pointer fields typed float* carry bf16 data -------------
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
-void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B);
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

@@ -111,3 +111,156 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
     STAMP(4, 4);
 }
 
+
+// ------------------------------------------------------------ synthetic env + leaf-range insert
+// Shared by k_env_step / k_per_add (dqn_replay.hip) and the actor variant of the forward kernels, where
+// every forward workgroup steps its own 16 envs and one surplus workgroup inserts the new leaves.
+#define RANGE_MAX 4096
+
+struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic envs; st == NULL => not an actor launch
+    DqnState *st;
+    float *states; int32_t *actions; float *rewards; float *observations; uint8_t *dones;
+    long long cap; float *tree; long long Nt; int L;
+    float *env_obs; unsigned long long seed; float p_done; int n;
+};
+
+// a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3) -- exactly reproducible on the CPU
+__device__ __forceinline__ float ih_normal(const u32x4 o) {
+    return (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;
+}
+
+// synthetic transition + ReplayBuffer.add + state = observation for envs [i0, i0+cnt); one work item per
+// (env, element): elements 0..D-1 are the next observation, element D is (reward, done). Thread `tr` of `nthr`.
+__device__ __forceinline__ void env_rows(int tr, int nthr, int i0, int cnt, unsigned long long c0, unsigned long long ec,
+                                         const EnvArgs &e, int D, const int32_t *acts, int acts_base) {
+    for (int t = tr; t < cnt * (D + 1); t += nthr) {
+        const int il = t / (D + 1), el = t - il * (D + 1), i = i0 + il;
+        const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)e.cap);
+        const u32x4 o = philox_draw(e.seed, ec, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
+        if (el < D) {
+            const float nx = ih_normal(o);
+            e.states[k * D + el] = e.env_obs[(long long)i * D + el];        // replay_buffer.py:59
+            e.observations[k * D + el] = nx;                                // :62
+            e.env_obs[(long long)i * D + el] = nx;                          // q_agent.py:183
+        } else {
+            const bool done = u01(o.x) < e.p_done;
+            float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
+            if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
+            e.actions[k] = acts[i - acts_base];                             // :60
+            e.rewards[k] = rew;                                             // :61
+            e.dones[k] = done ? 1 : 0;                                      // :63
+        }
+    }
+}
+
+// level-synchronous fallback through global memory (ring wrap, or n > RANGE_MAX). Whole workgroup.
+__device__ __forceinline__ void per_add_slow(float *tree, long long Nt, int L, unsigned long long c_base, int n,
+                                             float pmax, long long cap) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < n; i += nt)
+        tree[Nt + (long long)((c_base + (unsigned long long)i) % (unsigned long long)cap)] = pmax;
+    __threadfence_block();
+    __syncthreads();
+    for (int lvl = 1; lvl <= L; ++lvl) {
+        for (int i = tid; i < n; i += nt) {
+            const long long node = (Nt + (long long)((c_base + (unsigned long long)i) % (unsigned long long)cap)) >> lvl;
+            tree[node] = tree[2 * node] + tree[2 * node + 1];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// Leaf-range insert: new transitions occupy CONSECUTIVE leaves [a, a+n) at priority pmax, so the touched nodes
+// of every level are one contiguous range whose children are either in the previous level's range or one
+// untouched boundary sibling on each side (prefetched from HBM up front, all levels at once). Wide levels run
+// out of LDS with LDS-only barriers; once a level fits one wave it continues in registers (children by lane
+// shuffle); the last <= 2-node levels are wave-uniform scalar arithmetic. parent = left + right throughout.
+// Whole workgroup; lds: 2*(n+2) + 64 floats; requires n <= RANGE_MAX and a + n <= ring capacity.
+__device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int L, long long a, int n, float pmax, float *lds) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float *v0 = lds, *v1 = v0 + n + 2, *bl = v1 + n + 2, *br = bl + 32;
+    const long long first = Nt + a, last = Nt + a + n - 1;
+    for (int l = tid; l < L; l += nt) {
+        const long long lo = first >> l, hi = last >> l;
+        bl[l] = (lo & 1) ? tree[lo - 1] : 0.0f;
+        br[l] = (hi & 1) ? 0.0f : tree[hi + 1];
+    }
+    for (int j = tid; j < n; j += nt) { v0[j] = pmax; tree[first + j] = pmax; }
+    LDS_BARRIER();
+    float *cur = v0, *nxt = v1;
+    int l = 0;
+    for (; l < L; ++l) {
+        const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
+        const int cnt = (int)(phi - plo + 1);
+        if (hi - lo + 1 <= 64) break;
+        for (int j = tid; j < cnt; j += nt) {
+            const long long p = plo + j;
+            const float lv = (2 * p >= lo) ? cur[2 * p - lo] : bl[l];
+            const float rv = (2 * p + 1 <= hi) ? cur[2 * p + 1 - lo] : br[l];
+            const float v = lv + rv;
+            nxt[j] = v;
+            tree[p] = v;
+        }
+        LDS_BARRIER();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (tid < 64) {
+        const long long lo0 = first >> l, hi0 = last >> l;
+        float valr = (l < L && tid <= hi0 - lo0) ? cur[tid] : 0.0f;
+        const int blr = __float_as_int(tid < L ? bl[tid] : 0.0f), brr = __float_as_int(tid < L ? br[tid] : 0.0f);
+        for (; l < L; ++l) {
+            const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
+            if (hi - lo + 1 <= 2) break;
+            const int cnt = (int)(phi - plo + 1);
+            const long long p = plo + tid;
+            const int li = (int)(2 * p - lo), ri = li + 1;
+            float lv = __shfl(valr, li & 63, 64), rv = __shfl(valr, ri & 63, 64);
+            const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
+            const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
+            if (li < 0) lv = blv;
+            if (2 * p + 1 > hi) rv = brv;
+            const float v = lv + rv;
+            if (tid < cnt) tree[p] = v;
+            valr = v;
+        }
+        float n0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 0));
+        float n1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 1));
+        for (; l < L; ++l) {
+            const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
+            const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
+            const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
+            const float c_lo_l = (2 * plo >= lo) ? n0 : blv;
+            const float c_lo_r = (2 * plo + 1 <= hi) ? ((2 * plo + 1 == lo) ? n0 : n1) : brv;
+            const float p0 = c_lo_l + c_lo_r;
+            float p1 = 0.0f;
+            if (phi != plo) p1 = n1 + ((2 * phi + 1 <= hi) ? n1 : brv);      // 2*phi == hi here (value n1)
+            if (tid == 0) { tree[plo] = p0; if (phi != plo) tree[phi] = p1; }
+            n0 = p0; n1 = p1;
+        }
+    }
+}
+
+// ---- actor launch helpers (forward kernel + env step in one launch)
+// surplus workgroup: the leaf-range insert of this vector step (independent of the actions: new leaves get pmax)
+__device__ __forceinline__ void actor_tree_wg(const EnvArgs &e, unsigned long long c0, float *lds) {
+    const float pmax = e.st->pmax;
+    const long long a = (long long)(c0 % (unsigned long long)e.cap);
+    if (e.n <= RANGE_MAX && a + e.n <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, e.n, pmax, lds);
+    else per_add_slow(e.tree, e.Nt, e.L, c0, e.n, pmax, e.cap);
+}
+// the last workgroup of the launch to arrive commits the counters (every thread's stores depend on c0 / ec, so a
+// workgroup that reaches its barrier has finished reading them; no fence is needed for that)
+__device__ __forceinline__ void actor_commit(const EnvArgs &e, unsigned long long c0, unsigned long long ec, unsigned total_wgs) {
+    LDS_BARRIER();
+    if (threadIdx.x == 0) {
+        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
+        if (ticket == total_wgs - 1u) {
+            const unsigned long long c1 = c0 + (unsigned long long)e.n;
+            e.st->ring_counter = c1;                                                            // replay_buffer.py:64
+            e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
+            e.st->env_ctr = ec + 1ull;
+            e.st->arrive = 0;
+        }
+    }
+}

@@ -54,9 +54,6 @@ k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, floa
 // no physics. Per env i and vector step c: obs' ~ N(0,1)^D, r ~ N(0,1)
 // (+-100 on terminals), d ~ Bernoulli(p_done), all from Philox stream 3 and exactly
 // reproducible on the CPU: a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3).
-__device__ __forceinline__ float ih_normal(const u32x4 o) {
-    return (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;
-}
 
 __global__ void __launch_bounds__(256)
 k_synth_env(const DqnState *st, int n, int D, unsigned long long seed, float p_done,
@@ -455,193 +452,39 @@ k_per_top(DqnState *st, float *tree, int L) {
 }
 
 // ------------------------------------------------- leaf-range insert (ring add with PER)
-// New transitions occupy CONSECUTIVE leaves [a, a+n), so the touched nodes of every level are one
-// contiguous range whose children are either in the previous level's range (kept in LDS) or one
-// untouched boundary sibling on each side (prefetched from HBM up front, all levels at once).
-// The whole bottom-up refresh then runs out of LDS: one barrier per level, global stores only.
-// Same arithmetic as the level-synchronous path: parent = left + right. One workgroup.
-#define RANGE_MAX 4096
-__device__ void per_add_range(float *tree, long long Nt, int L, long long a, int n, float pmax,
-                              float *v0, float *v1, float *bl, float *br) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const long long first = Nt + a, last = Nt + a + n - 1;
-    for (int l = tid; l < L; l += nt) {                       // boundary siblings of every level
-        const long long lo = first >> l, hi = last >> l;
-        bl[l] = (lo & 1) ? tree[lo - 1] : 0.0f;
-        br[l] = (hi & 1) ? 0.0f : tree[hi + 1];
-    }
-    for (int j = tid; j < n; j += nt) { v0[j] = pmax; tree[first + j] = pmax; }
-    __syncthreads();                                         // boundary loads have landed in LDS
-    float *cur = v0, *nxt = v1;
-    for (int l = 0; l < L; ++l) {
-        const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-        const int cnt = (int)(phi - plo + 1);
-        for (int j = tid; j < cnt; j += nt) {
-            const long long p = plo + j;
-            const float lv = (2 * p >= lo) ? cur[2 * p - lo] : bl[l];
-            const float rv = (2 * p + 1 <= hi) ? cur[2 * p + 1 - lo] : br[l];
-            const float v = lv + rv;
-            nxt[j] = v;
-            tree[p] = v;
-        }
-        LDS_BARRIER();
-        float *t = cur; cur = nxt; nxt = t;
-    }
-}
-
-// level-synchronous fallback through global memory (ring wrap, or n > RANGE_MAX)
-__device__ void per_add_slow(float *tree, long long Nt, int L, unsigned long long c_base, int n, float pmax,
-                             long long cap) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < n; i += nt)
-        tree[Nt + (long long)((c_base + (unsigned long long)i) % (unsigned long long)cap)] = pmax;
-    __threadfence_block();
-    __syncthreads();
-    for (int lvl = 1; lvl <= L; ++lvl) {
-        for (int i = tid; i < n; i += nt) {
-            const long long node = (Nt + (long long)((c_base + (unsigned long long)i) % (unsigned long long)cap)) >> lvl;
-            tree[node] = tree[2 * node] + tree[2 * node + 1];
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
+// device code: per_add_range_wg / per_add_slow in dqn_per_device.h
 __global__ void __launch_bounds__(1024)
 k_per_add(const DqnState *st, float *tree, long long Nt, int L, int n, long long cap) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned long long c_base = st->ring_counter - (unsigned long long)n;   // slots just written
     const long long a = (long long)(c_base % (unsigned long long)cap);
     const float pmax = st->pmax;
-    if (n <= RANGE_MAX && a + n <= cap) {
-        float *v0 = lds, *v1 = v0 + n + 2, *bl = v1 + n + 2, *br = bl + 32;
-        per_add_range(tree, Nt, L, a, n, pmax, v0, v1, bl, br);
-    } else {
-        per_add_slow(tree, Nt, L, c_base, n, pmax, cap);
-    }
+    if (n <= RANGE_MAX && a + n <= cap) per_add_range_wg(tree, Nt, L, a, n, pmax, lds);
+    else per_add_slow(tree, Nt, L, c_base, n, pmax, cap);
 }
 
-// ------------------------------------------------------------- fused vector env step
-// q_agent.py:177-183 for n synthetic envs in ONE workgroup: synthetic transition (as k_synth_env),
-// ReplayBuffer.add of the n rows (replay_buffer.py:58-65), state = observation, and -- with PER --
-// the leaf-range insert at the running max priority. Counters are committed by thread 0 at the end.
+// ------------------------------------------------------------- vector env step, one workgroup
+// q_agent.py:177-183 for n synthetic envs given their actions: synthetic transition, ReplayBuffer.add of the
+// n rows, state = observation, and -- with PER -- the leaf-range insert. (The device-resident actor loop uses
+// the fused forward+env launch instead; this kernel serves env steps whose actions come from elsewhere.)
 __global__ void __launch_bounds__(1024)
-k_env_step(DqnState *st, float *states, int32_t *actions, float *rewards, float *observations, uint8_t *dones,
-           long long cap, int D, float *tree, long long Nt, int L, float *env_obs, const int32_t *env_a, int n,
-           unsigned long long seed, float p_done) {
+k_env_step(EnvArgs e, int D, const int32_t *env_a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    STAMP(1, 0);
-    const unsigned long long c0 = st->ring_counter, ec = st->env_ctr;
-    const float pmax = st->pmax;
-    const long long a = (long long)(c0 % (unsigned long long)cap);
-    const bool fast = tree && n <= RANGE_MAX && a + n <= cap;
-    float *v0 = lds, *v1 = v0 + n + 2, *bl = v1 + n + 2, *br = bl + 32;
-    if (fast) {                                              // issue the boundary-sibling loads first
-        const long long first = Nt + a, last = Nt + a + n - 1;
-        for (int l = tid; l < L; l += nt) {
-            const long long lo = first >> l, hi = last >> l;
-            bl[l] = (lo & 1) ? tree[lo - 1] : 0.0f;
-            br[l] = (hi & 1) ? 0.0f : tree[hi + 1];
-        }
+    const int tid = threadIdx.x;
+    const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
+    const float pmax = e.st->pmax;
+    const long long a = (long long)(c0 % (unsigned long long)e.cap);
+    env_rows(tid, blockDim.x, 0, e.n, c0, ec, e, D, env_a, 0);
+    if (e.tree) {
+        if (e.n <= RANGE_MAX && a + e.n <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, e.n, pmax, lds);
+        else per_add_slow(e.tree, e.Nt, e.L, c0, e.n, pmax, e.cap);
     }
-    // one work item per (env, element): elements 0..D-1 are the next observation, element D is (r, done)
-    for (int t = tid; t < n * (D + 1); t += nt) {
-        const int i = t / (D + 1), e = t - i * (D + 1);
-        const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)cap);
-        const u32x4 o = philox_draw(seed, ec, (uint32_t)t, DQN_STREAM_ENV);
-        if (e < D) {
-            const float nx = ih_normal(o);
-            states[k * D + e] = env_obs[(long long)i * D + e];          // :59
-            observations[k * D + e] = nx;                               // :62
-            env_obs[(long long)i * D + e] = nx;                         // q_agent.py:183
-        } else {
-            const bool done = u01(o.x) < p_done;
-            float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
-            if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
-            actions[k] = env_a[i];                                      // :60
-            rewards[k] = rew;                                           // :61
-            dones[k] = done ? 1 : 0;                                    // :63
-        }
-    }
-    STAMP(1, 1);
-    if (tree) {
-        if (fast) {
-            const long long first = Nt + a, last = Nt + a + n - 1;
-            for (int j = tid; j < n; j += nt) { v0[j] = pmax; tree[first + j] = pmax; }
-            LDS_BARRIER();                                   // boundary values + leaf values are in LDS
-            STAMP(1, 2);
-            float *cur = v0, *nxt = v1;
-            int l = 0;
-            for (; l < L; ++l) {
-                const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-                const int cnt = (int)(phi - plo + 1);
-                if (hi - lo + 1 <= 64) break;                // the rest fits one wave: no more barriers
-                for (int j = tid; j < cnt; j += nt) {
-                    const long long p = plo + j;
-                    const float lv = (2 * p >= lo) ? cur[2 * p - lo] : bl[l];
-                    const float rv = (2 * p + 1 <= hi) ? cur[2 * p + 1 - lo] : br[l];
-                    const float v = lv + rv;
-                    nxt[j] = v;
-                    tree[p] = v;
-                }
-                LDS_BARRIER();
-                float *t = cur; cur = nxt; nxt = t;
-            }
-            if (tid < 64) {
-                // one wave, registers only: lane j holds node lo+j of the current level; children come
-                // from two lane shuffles, the boundary siblings of level l live in lane l
-                const long long lo0 = first >> l, hi0 = last >> l;
-                float valr = (tid <= hi0 - lo0) ? cur[tid] : 0.0f;
-                const int blr = __float_as_int(tid < L ? bl[tid] : 0.0f), brr = __float_as_int(tid < L ? br[tid] : 0.0f);
-                for (; l < L; ++l) {
-                    const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-                    if (hi - lo + 1 <= 2) break;                 // one or two nodes left: finish serially
-                    const int cnt = (int)(phi - plo + 1);
-                    const long long p = plo + tid;
-                    const int li = (int)(2 * p - lo), ri = li + 1;
-                    float lv = __shfl(valr, li & 63, 64), rv = __shfl(valr, ri & 63, 64);
-                    const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
-                    const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
-                    if (li < 0) lv = blv;
-                    if (2 * p + 1 > hi) rv = brv;
-                    const float v = lv + rv;
-                    if (tid < cnt) tree[p] = v;
-                    valr = v;
-                }
-                // top of the path: <= 2 nodes per level, wave-uniform arithmetic, no cross-lane traffic
-                float n0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 0));
-                float n1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 1));
-                for (; l < L; ++l) {
-                    const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-                    const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
-                    const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
-                    // children of parent plo: nodes 2*plo, 2*plo+1 ; of parent phi (if different): 2*phi, 2*phi+1
-                    const float c_lo_l = (2 * plo >= lo) ? n0 : blv;                         // 2*plo is lo or lo-1
-                    const float c_lo_r = (2 * plo + 1 <= hi) ? ((2 * plo + 1 == lo) ? n0 : n1) : brv;
-                    const float p0 = c_lo_l + c_lo_r;
-                    float p1 = 0.0f;
-                    if (phi != plo) {                            // two parents: lo is a right child, hi a left child
-                        const float c_hi_r = (2 * phi + 1 <= hi) ? n1 : brv;
-                        p1 = n1 + c_hi_r;                        // 2*phi == hi here, its value is n1
-                        (void)c_hi_r;
-                    }
-                    if (tid == 0) { tree[plo] = p0; if (phi != plo) tree[phi] = p1; }
-                    n0 = p0; n1 = p1;
-                }
-            }
-        } else {
-            per_add_slow(tree, Nt, L, c0, n, pmax, cap);
-        }
-    }
-    STAMP(1, 3);
     __syncthreads();
-    STAMP(1, 4);
     if (tid == 0) {
-        const unsigned long long c1 = c0 + (unsigned long long)n;
-        st->ring_counter = c1;                                                            // :64
-        st->size = (long long)(c1 < (unsigned long long)cap ? c1 : (unsigned long long)cap);   // :65
-        st->env_ctr = ec + 1ull;
+        const unsigned long long c1 = c0 + (unsigned long long)e.n;
+        e.st->ring_counter = c1;                                                            // :64
+        e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
+        e.st->env_ctr = ec + 1ull;
     }
 }
 
@@ -712,12 +555,9 @@ void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long 
     hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, st, tree, Nt, L, n, cap);
 }
 
-void launch_env_step(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
-                     float *observations, uint8_t *dones, long long N, int D, float *tree, long long Ntree, int L,
-                     float *env_obs, const int32_t *env_a, int n, unsigned long long seed, float p_done) {
-    const size_t lds = (tree && n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(n + 2) + 64) : 0;
-    hipLaunchKernelGGL(k_env_step, dim3(1), dim3(pow2_threads(n * (D + 1), 64, 1024)), lds, st_, st, states, actions, rewards,
-                       observations, dones, N, D, tree, Ntree, L, env_obs, env_a, n, seed, p_done);
+void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *env_a) {
+    const size_t lds = (e.tree && e.n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(e.n + 2) + 64) : 0;
+    hipLaunchKernelGGL(k_env_step, dim3(1), dim3(pow2_threads(e.n * (D + 1), 64, 1024)), lds, st_, e, D, env_a);
 }
 
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
