@@ -3,7 +3,10 @@
 #pragma once
 #include "dqn_device.h"
 
-#define PW_TOP 10
+// The tree is cut at depth TOP = min(L, PW_TOP): subtrees below the cut hold 2^(L-TOP) leaves (64 at L = 20), so
+// that the <= 64-items-per-wave register path almost always applies even when the newest leaves (inserted at the
+// running max priority, contiguous) attract many samples; the dense top is rebuilt by k_per_top.
+#define PW_TOP 14
 #define PW_BOT 21            // bottom levels handled below the dense top image: L - PW_TOP <= 21 (L <= 31)
 
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }

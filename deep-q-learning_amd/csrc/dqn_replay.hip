@@ -262,6 +262,7 @@ k_per_write(DqnState *st, float *tree, unsigned long long *stamp, long long N, i
 // Only LDS barriers inside the loops. One workgroup, IPT items per thread held in registers.
 __device__ __forceinline__ unsigned pw_hash(unsigned key, unsigned mask) { return (key * 2654435761u) >> 7 & mask; }
 
+#define PWL_TOP 10           // dense-top depth of this single-workgroup variant (2^11 floats of LDS)
 template <int IPT>
 __global__ void __launch_bounds__(1024)
 k_per_write_lds(DqnState *st, float *tree, long long N, int L, const int32_t *__restrict__ idx,
@@ -269,7 +270,7 @@ k_per_write_lds(DqnState *st, float *tree, long long N, int L, const int32_t *__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ float red[1024];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int TOP = L < PW_TOP ? L : PW_TOP;
+    const int TOP = L < PWL_TOP ? L : PWL_TOP;
     const unsigned mask = (unsigned)TS - 1u;
     int *keys0 = reinterpret_cast<int *>(smem);             // two hash tables, alternating per level
     float *vals0 = reinterpret_cast<float *>(keys0 + TS);
@@ -433,12 +434,21 @@ k_per_write_sorted(DqnState *st, float *tree, long long N, int L, const int32_t 
 
 __global__ void __launch_bounds__(1024)
 k_per_top(DqnState *st, float *tree, int L) {
+    // depth TOP holds n = 2^TOP nodes (already final in HBM); depth TOP-1 is summed straight from them
+    // (coalesced pair loads), the levels above are reduced out of an LDS image of 2^TOP floats.
     extern __shared__ __attribute__((aligned(16))) float top[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int TOP = L < PW_TOP ? L : PW_TOP, n = 1 << TOP;
-    for (int j = tid; j < n; j += nt) top[n + j] = tree[n + j];
+    const int TOP = L < PW_TOP ? L : PW_TOP;
+    if (TOP == 0) { if (tid == 0) st->epoch += 1ull; return; }
+    const int h = 1 << (TOP - 1);                            // nodes at depth TOP-1: indices [h, 2h)
+    for (int j = tid; j < h; j += nt) {
+        const float2 c = *reinterpret_cast<const float2 *>(tree + 2 * (h + j));
+        const float v = c.x + c.y;
+        top[h + j] = v;
+        tree[h + j] = v;
+    }
     __syncthreads();
-    for (int d = TOP - 1; d >= 0; --d) {
+    for (int d = TOP - 2; d >= 0; --d) {
         const int cnt = 1 << d;
         for (int j = tid; j < cnt; j += nt) {
             const int p = cnt + j;
@@ -536,7 +546,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
     if (mode != 2 && B <= 4096 && L <= 31) {
         int TS = 128;
         while (TS < 2 * B) TS <<= 1;                          // load factor <= 0.5
-        const int TOP = L < PW_TOP ? L : PW_TOP;
+        const int TOP = L < PWL_TOP ? L : PWL_TOP;
         const size_t lds = (size_t)TS * 16 + sizeof(float) * (size_t)(2 << TOP);
         const int ipt = (B + threads - 1) / threads;
         if (ipt <= 1)      hipLaunchKernelGGL((k_per_write_lds<1>), dim3(1), dim3(threads), lds, st_, st, tree, N, L, idx, val, B, mode, alpha, eps, TS);
@@ -562,15 +572,13 @@ void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *en
 
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
     const int TOP = L < PW_TOP ? L : PW_TOP;
-    const int n = 1 << TOP;
-    hipLaunchKernelGGL(k_per_top, dim3(1), dim3(n < 1024 ? (n < 64 ? 64 : n) : 1024), sizeof(float) * 2 * n, st_, st, tree, L);
+    const int n = 1 << TOP;                                   // LDS image: indices [0, n) = depths 0 .. TOP-1
+    hipLaunchKernelGGL(k_per_top, dim3(1), dim3(n / 2 < 1024 ? (n / 2 < 64 ? 64 : n / 2) : 1024), sizeof(float) * n, st_, st, tree, L);
 }
 
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
                              const float *val, int B, int mode, float alpha, float eps) {
     hipLaunchKernelGGL(k_per_write_sorted, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, idx, val, B, mode,
                        alpha, eps);
-    const int TOP = L < PW_TOP ? L : PW_TOP;
-    const int n = 1 << TOP;
-    hipLaunchKernelGGL(k_per_top, dim3(1), dim3(n < 1024 ? (n < 64 ? 64 : n) : 1024), sizeof(float) * 2 * n, st_, st, tree, L);
+    launch_per_top(st_, st, tree, L);
 }
