@@ -17,6 +17,7 @@
 
 // ------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
+thread_local hipEvent_t g_prof_ev0 = nullptr, g_prof_ev1 = nullptr;
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
@@ -109,11 +110,20 @@ static void L_dw(dqn_handle *h, hipStream_t s, int B, float *loss_out, int bump,
     else launch_dw(s, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->grad, h->loss_part, loss_out, h->st, bump, ad, pw);
 }
 
-// record an event after the launch just enqueued (profiling mode only)
-static void mark(dqn_handle *h, hipStream_t st, const char *name) {
+// profiling mode: arm() before a launch hands the next (start, stop) event pair to DQN_LAUNCH, mark() names it
+static void arm(dqn_handle *h) {
     if (!h->profiling) return;
-    if (h->ev_used == h->events.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; h->events.push_back(e); }
-    (void)hipEventRecord(h->events[h->ev_used++], st);
+    while (h->events.size() < h->ev_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        h->events.push_back(e);
+    }
+    g_prof_ev0 = h->events[h->ev_used]; g_prof_ev1 = h->events[h->ev_used + 1];
+}
+static void mark(dqn_handle *h, hipStream_t st, const char *name) {
+    (void)st;
+    if (!h->profiling) return;
+    h->ev_used += 2;
     h->ev_names.push_back(name);
 }
 
@@ -464,6 +474,7 @@ static AdamArgs adam_args(dqn_handle *h) {
 
 static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
     // the batch indices come from dqn_per_sample's stratified descent: non-decreasing
+    arm(h);
     launch_per_write_sorted(st, h->st, h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
                             h->cfg.per_alpha, h->cfg.per_eps);
     mark(h, st, "per_update");
@@ -474,6 +485,7 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
 // parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
 static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fuse_pw = false) {
     // q_agent.py:147-153 sample_batch
+    arm(h);
     if (h->cfg.use_per)
         launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
                           h->dones, h->cfg.obs_dim, B, 0.f, h->cfg.seed, 0, 1, h->bs, h->ba, h->br, h->bs2, h->bd,
@@ -486,6 +498,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, true),
                      make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),
                      make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false) };
+    arm(h);
     L_fwd(h, st, p, 3, B);
     mark(h, st, "qnet_fwd_x3");
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
@@ -495,17 +508,20 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
+    arm(h);
     L_bwd(h, st, g, B);
     mark(h, st, "td_bwd_rows");
     PwArgs pw{};
     if (fuse_pw && h->cfg.use_per)
         pw = PwArgs{h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, h->cfg.per_alpha, h->cfg.per_eps};
+    arm(h);
     L_dw(h, st, B, h->loss_dev, 1, fuse_adam ? adam_args(h) : AdamArgs{}, pw);
     mark(h, st, fuse_adam ? (pw.tree ? "dw_adam_perwrite" : "dw_adam") : "dw");
-    if (pw.tree) { launch_per_top(st, h->st, h->tree, h->L); mark(h, st, "per_top"); }
+    if (pw.tree) { arm(h); launch_per_top(st, h->st, h->tree, h->L); mark(h, st, "per_top"); }
 }
 
 static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
+    arm(h);
     enqueue_adam(h, st);                                           // q_learning_functions.py:24-25
     mark(h, st, "adam");
     if (h->cfg.use_per) enqueue_per_writeback(h, B, st);
@@ -534,6 +550,7 @@ static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st) {
     e.st = h->st; e.states = h->states; e.actions = h->actions; e.rewards = h->rewards; e.observations = h->observations;
     e.dones = h->dones; e.cap = h->cfg.capacity; e.tree = h->cfg.use_per ? h->tree : nullptr; e.Nt = h->Ntree; e.L = h->L;
     e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
+    arm(h);
     L_fwd(h, st, &p, 1, n_envs, &e);
     mark(h, st, "actor_step");
 }
@@ -646,9 +663,8 @@ extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {
 // --------------------------------------------------------------------------- profiling
 extern "C" int dqn_profile_begin(dqn_handle *h, void *stream) {
     REQUIRE(h, "null argument");
+    (void)stream;
     h->profiling = true; h->ev_used = 0; h->ev_names.clear();
-    if (h->events.empty()) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->events.push_back(e); }
-    HIP_TRY(hipEventRecord(h->events[h->ev_used++], (hipStream_t)stream));
     return DQN_OK;
 }
 
@@ -656,11 +672,12 @@ extern "C" int dqn_profile_end(dqn_handle *h, void *stream, char *names, int32_t
                                int32_t max_entries, int32_t *count) {
     REQUIRE(h && names && ms && count, "null argument");
     h->profiling = false;
+    g_prof_ev0 = nullptr; g_prof_ev1 = nullptr;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     int n = (int)h->ev_names.size();
     if (n > max_entries) n = max_entries;
     for (int i = 0; i < n; ++i) {
-        HIP_TRY(hipEventElapsedTime(&ms[i], h->events[i], h->events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], h->events[2 * i], h->events[2 * i + 1]));
         snprintf(names + (size_t)i * name_stride, name_stride, "%s", h->ev_names[i]);
     }
     *count = n;

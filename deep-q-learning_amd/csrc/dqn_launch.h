@@ -4,7 +4,23 @@
 #include <stdint.h>
 #include "dqn_device.h"
 
+#include <hip/hip_ext.h>
+
 struct EnvArgs;   // dqn_per_device.h
+
+// Kernel launch used by the hot-path launchers. In profiling mode (dqn_profile_begin) the API arms a pair of
+// events before each launch; the launch is then issued with hipExtLaunchKernelGGL so that the two events carry the
+// dispatch's own start / stop timestamps (what rocprofv3 reports), not host-side bracketing.
+extern thread_local hipEvent_t g_prof_ev0, g_prof_ev1;
+#define DQN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                    \
+    do {                                                                                                      \
+        if (g_prof_ev0) {                                                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_prof_ev0, g_prof_ev1, 0, __VA_ARGS__); \
+            g_prof_ev0 = nullptr; g_prof_ev1 = nullptr;                                                       \
+        } else {                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                \
+        }                                                                                                     \
+    } while (0)
 
 // ----- network geometry -----------------------------------------------------------------
 // Flat parameter layout (haiku leaf order, w is [in,out] row-major; LunarLander/dddqn.py:19-22):

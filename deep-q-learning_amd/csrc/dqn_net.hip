@@ -374,7 +374,7 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
     size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 16);
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { hipLaunchKernelGGL((k_qnet_fwd<A1, A2>), grid, block, lds, s, m, ps, B, ea); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2>), grid, block, lds, s, m, ps, B, ea); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
@@ -603,7 +603,7 @@ void launch_bwd_rows(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, D
     const dim3 grid((B + 15) / 16), block(256);
     const size_t lds = sizeof(float) * (16 * 20 + 16 * (m.H2 + 4) + 16);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define BWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { hipLaunchKernelGGL((k_bwd_rows<A1, A2>), grid, block, lds, s, m, g, B, st); return; }
+#define BWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_bwd_rows<A1, A2>), grid, block, lds, s, m, g, B, st); return; }
     BWD_CASE(1, 1) BWD_CASE(1, 2) BWD_CASE(1, 4) BWD_CASE(2, 1) BWD_CASE(2, 2) BWD_CASE(2, 4)
     BWD_CASE(4, 1) BWD_CASE(4, 2) BWD_CASE(4, 4)
 #undef BWD_CASE
@@ -790,7 +790,7 @@ void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph
                const PwArgs &pw) {
     const int tiles = (m.H1 / 16) * (m.H2 / 16) + m.KQ1 * (m.H1 / 16) + m.H2 / 16;
     const int extra = pw.tree ? (pw.B + 63) / 64 : 0;
-    hipLaunchKernelGGL(k_dw, dim3(tiles + extra), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, B, grad,
+    DQN_LAUNCH(k_dw, dim3(tiles + extra), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, B, grad,
                        loss_part, loss_out, st, bump_ctr, adam, pw, tiles);
 }
 
@@ -820,7 +820,7 @@ void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, c
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
     int blocks = (int)((m.P + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, m, st, params, grad, mu, nu, pack, adamw, b1, b2,
+    DQN_LAUNCH(k_adam, dim3(blocks), dim3(256), 0, s, m, st, params, grad, mu, nu, pack, adamw, b1, b2,
                        eps, wd, grad_scale);
 }
 

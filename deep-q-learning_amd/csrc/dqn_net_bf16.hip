@@ -302,7 +302,7 @@ void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes
     size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 16);
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { hipLaunchKernelGGL((k_qnet_fwd16<A1, A2>), grid, block, lds, s, m, d, ps, B, ea); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2>), grid, block, lds, s, m, d, ps, B, ea); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
@@ -443,7 +443,7 @@ void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int
     const dim3 grid(tiles16(B)), block(256);
     const size_t lds = 2 * (16 * 40 + 16 * (d.KQH * 32 + 8)) + 4 * 16;
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define BWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { hipLaunchKernelGGL((k_bwd_rows16<A1, A2>), grid, block, lds, s, m, d, g, B, st); return; }
+#define BWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_bwd_rows16<A1, A2>), grid, block, lds, s, m, d, g, B, st); return; }
     BWD_CASE(1, 1) BWD_CASE(1, 2) BWD_CASE(1, 4) BWD_CASE(2, 1) BWD_CASE(2, 2) BWD_CASE(2, 4)
     BWD_CASE(4, 1) BWD_CASE(4, 2) BWD_CASE(4, 4)
 #undef BWD_CASE
@@ -574,7 +574,7 @@ void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const floa
     const int tiles = (m.H1 / 16) * (m.H2 / 16) + m.KQ1 * (m.H1 / 16) + m.H2 / 16;
     const int extra = pw.tree ? (pw.B + 63) / 64 : 0;
     auto bf = [](const float *p) { return reinterpret_cast<const __bf16 *>(p); };
-    hipLaunchKernelGGL(k_dw16, dim3(tiles + extra), dim3(256), 0, s, m, d, bf(px), bf(ph1), bf(ph2), bf(pdz1), bf(pdz2),
+    DQN_LAUNCH(k_dw16, dim3(tiles + extra), dim3(256), 0, s, m, d, bf(px), bf(ph1), bf(ph2), bf(pdz1), bf(pdz2),
                        bf(pdz3), B, grad, loss_part, loss_out, st, bump_ctr, adam, pw, tiles);
 }
 
@@ -600,6 +600,6 @@ void launch_adam_bf16(hipStream_t s, const NetDims &m, DqnState *st, float *para
                       float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
     int blocks = (int)((m.P + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam16, dim3(blocks), dim3(256), 0, s, m, make_dims16(m), st, params, grad, mu, nu,
+    DQN_LAUNCH(k_adam16, dim3(blocks), dim3(256), 0, s, m, make_dims16(m), st, params, grad, mu, nu,
                        reinterpret_cast<__bf16 *>(pack), adamw, b1, b2, eps, wd, grad_scale);
 }

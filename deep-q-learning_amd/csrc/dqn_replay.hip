@@ -530,7 +530,7 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        const float *observations, const uint8_t *dones, int D, int B, float beta,
                        unsigned long long seed, unsigned long long ctr, int from_state,
                        float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw) {
-    hipLaunchKernelGGL(k_per_sample, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, states, actions,
+    DQN_LAUNCH(k_per_sample, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, states, actions,
                        rewards, observations, dones, D, B, beta, seed, ctr, from_state, s, a, r, s2, d, idx, w_raw);
 }
 
@@ -567,18 +567,18 @@ void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long 
 
 void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *env_a) {
     const size_t lds = (e.tree && e.n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(e.n + 2) + 64) : 0;
-    hipLaunchKernelGGL(k_env_step, dim3(1), dim3(pow2_threads(e.n * (D + 1), 64, 1024)), lds, st_, e, D, env_a);
+    DQN_LAUNCH(k_env_step, dim3(1), dim3(pow2_threads(e.n * (D + 1), 64, 1024)), lds, st_, e, D, env_a);
 }
 
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
     const int TOP = L < PW_TOP ? L : PW_TOP;
     const int n = 1 << TOP;                                   // LDS image: indices [0, n) = depths 0 .. TOP-1
-    hipLaunchKernelGGL(k_per_top, dim3(1), dim3(n / 2 < 1024 ? (n / 2 < 64 ? 64 : n / 2) : 1024), sizeof(float) * n, st_, st, tree, L);
+    DQN_LAUNCH(k_per_top, dim3(1), dim3(n / 2 < 1024 ? (n / 2 < 64 ? 64 : n / 2) : 1024), sizeof(float) * n, st_, st, tree, L);
 }
 
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
                              const float *val, int B, int mode, float alpha, float eps) {
-    hipLaunchKernelGGL(k_per_write_sorted, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, idx, val, B, mode,
+    DQN_LAUNCH(k_per_write_sorted, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, idx, val, B, mode,
                        alpha, eps);
     launch_per_top(st_, st, tree, L);
 }

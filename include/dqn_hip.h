@@ -173,9 +173,9 @@ int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps, int32_t n
 int dqn_sync_target(dqn_handle *h, void *stream);
 
 /* per-kernel timing with HIP events on `stream` (bench.py's live roofline measurement): between
- * begin and end every library launch is run eagerly and bracketed by events; end synchronises and
- * returns up to max_entries (name, elapsed ms) pairs, names as NUL-terminated strings of
- * name_stride bytes each. */
+ * begin and end every hot-path launch is run eagerly with hipExtLaunchKernelGGL start/stop events (the
+ * dispatch's own timestamps); end synchronises and returns up to max_entries (name, elapsed ms) pairs,
+ * names as NUL-terminated strings of name_stride bytes each. A name covering two kernels reports the first. */
 int dqn_profile_begin(dqn_handle *h, void *stream);
 int dqn_profile_end(dqn_handle *h, void *stream, char *names_host, int32_t name_stride, float *ms_host,
                     int32_t max_entries, int32_t *count_host);
