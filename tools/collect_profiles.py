@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of a gpurun profiling session into profiles/ (tracked):
+    python tools/collect_profiles.py <tag> <round>      e.g.  r01final r01
+Inputs under gpurun_out/: prof_<tag>/ (rocprofv3 --kernel-trace --stats of bench.py), pmc_<tag>.json
+(tools/prof_pmc.sh), bench_<tag>.json, sweep_*.json."""
+import csv
+import glob
+import os
+import shutil
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+f = glob.glob(f"gpurun_out/prof_{tag}/*/*kernel_stats.csv")[0]
+with open(f"profiles/{rnd}_kernel_stats.csv", "w", newline="") as o:
+    w = csv.writer(o)
+    cols = ["Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]
+    w.writerow(["Name"] + cols)
+    for r in csv.DictReader(open(f)):
+        w.writerow([r["Name"].split("(")[0][:100]] + [r[k] for k in cols])
+f = glob.glob(f"gpurun_out/prof_{tag}/*/*kernel_trace.csv")[0]
+tr = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("k_", "void k_"))]
+tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+# one inner-loop iteration of the f32 loop: 4 actor launches followed by the update's kernels
+i0 = len(tr) // 3
+while not ("k_per_sample" in tr[i0]["Kernel_Name"] and "fwd<" in tr[i0 - 1]["Kernel_Name"]):
+    i0 += 1
+i0 -= 4
+with open(f"profiles/{rnd}_kernel_trace_one_step.csv", "w", newline="") as o:
+    w = csv.writer(o)
+    w.writerow(["kernel", "start_ns_rel", "duration_ns", "grid", "workgroup", "lds_bytes"])
+    t0 = int(tr[i0]["Start_Timestamp"])
+    for r in tr[i0:i0 + 10]:
+        w.writerow([r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]) - t0,
+                    int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"]])
+for src, dst in ((f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc.json"),
+                 (f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json")):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+for s in glob.glob("gpurun_out/sweep_*.json"):
+    shutil.copy(s, f"profiles/{rnd}_{os.path.basename(s)}")
+print(open(f"profiles/{rnd}_kernel_trace_one_step.csv").read())
