@@ -63,6 +63,7 @@ SIGNATURES = {
     "dqn_env_reset": [_P, _P, _I32, _F, _P],
     "dqn_actor_step": [_P, _I32, _P],
     "dqn_train_iters": [_P, _I32, _I32, _I32, _I32, _P],
+    "dqn_actor_backward": [_P, _I32, _I32, _I32, _P],
     "dqn_profile_begin": [_P, _P],
     "dqn_profile_end": [_P, _P, _P, _I32, _P, _I32, C.POINTER(_I32)],
     "dqn_comm_unique_id": [_P],

@@ -516,15 +516,17 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
         pw = PwArgs{h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, h->cfg.per_alpha, h->cfg.per_eps};
     arm(h);
     L_dw(h, st, B, h->loss_dev, 1, fuse_adam ? adam_args(h) : AdamArgs{}, pw);
-    mark(h, st, fuse_adam ? (pw.tree ? "dw_adam_perwrite" : "dw_adam") : "dw");
+    mark(h, st, fuse_adam ? (pw.tree ? "dw_adam_perwrite" : "dw_adam") : (pw.tree ? "dw_perwrite" : "dw"));
     if (pw.tree) { arm(h); launch_per_top(st, h->st, h->tree, h->L); mark(h, st, "per_top"); }
 }
 
+// second half of an update when a gradient all-reduce sits in between: only the optimizer is left (the PER
+// write-back does not depend on the all-reduce and already rode in the backward half's dW launch)
 static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
+    (void)B;
     arm(h);
     enqueue_adam(h, st);                                           // q_learning_functions.py:24-25
     mark(h, st, "adam");
-    if (h->cfg.use_per) enqueue_per_writeback(h, B, st);
 }
 
 // the whole Agent._step. Single GPU: optimizer fused into the dW epilogue, and the PER write-back waves
@@ -535,7 +537,7 @@ static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing)
     if (h->world == 1) {
         enqueue_backward(h, B, st, true, true);
     } else {
-        enqueue_backward(h, B, st);
+        enqueue_backward(h, B, st, false, true);
         enqueue_apply(h, B, st);
     }
 }
@@ -588,7 +590,7 @@ extern "C" int dqn_update_fused(dqn_handle *h, int32_t B, void *stream) {
 extern "C" int dqn_update_backward(dqn_handle *h, int32_t B, void *stream) {
     int rc = check_B(h, B); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return run_captured(h, &h->graphs[B].bwd, st, [&] { enqueue_backward(h, B, st); });
+    return run_captured(h, &h->graphs[B].bwd, st, [&] { enqueue_backward(h, B, st, false, true); });
 }
 extern "C" int dqn_update_apply(dqn_handle *h, int32_t B, void *stream) {
     int rc = check_B(h, B); if (rc) return rc;
@@ -631,6 +633,21 @@ extern "C" int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream) {
             "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
     return run_captured(h, &h->graphs[-n_envs].actor, st, [&] { enqueue_actor(h, n_envs, st); });
+}
+
+/* env_steps vector env steps + the backward half of one update as ONE graph launch (data-parallel step:
+ * this, then the gradient all-reduce, then dqn_update_apply) */
+extern "C" int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_envs, int32_t B, void *stream) {
+    int rc = check_B(h, B); if (rc) return rc;
+    REQUIRE(env_steps >= 0 && env_steps <= 64, "env_steps out of range");
+    REQUIRE(env_steps == 0 || (n_envs >= 1 && n_envs <= h->cfg.max_batch && n_envs <= h->cfg.capacity),
+            "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const std::vector<int> key{-1, env_steps, n_envs, B};
+    return run_captured(h, &h->loop_graphs[key], st, [&] {
+        for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st);
+        enqueue_backward(h, B, st, false, true);
+    });
 }
 
 /* n_iters x (env_steps vector env steps + one update) as ONE graph launch */

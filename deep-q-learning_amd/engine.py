@@ -320,6 +320,11 @@ class Engine:
         """n_iters x (env_steps vector env steps + one update) in one graph launch (q_agent.py:174-187)"""
         L.check(self.lib.dqn_train_iters(self.h, n_iters, env_steps, getattr(self, "n_envs", 0), B, self._s(stream)))
 
+    def actor_backward(self, env_steps, B, stream=None):
+        """data-parallel iteration, first half: env_steps vector env steps + sample..grads (+ PER write-back) in one
+        graph launch; then all-reduce DQN_BUF_GRAD and call update_apply"""
+        L.check(self.lib.dqn_actor_backward(self.h, env_steps, getattr(self, "n_envs", 0), B, self._s(stream)))
+
     # ------------------------------------------------------------------ profiling
     def profile_begin(self, stream=None):
         L.check(self.lib.dqn_profile_begin(self.h, self._s(stream)))

@@ -148,8 +148,8 @@ int dqn_train_step(dqn_handle *h, const float *s, const float *targets, int32_t 
  * hipGraph. With world_size > 1 use the two halves around dqn_allreduce_grads (or a
  * torch.distributed all_reduce on DQN_BUF_GRAD). */
 int dqn_update_fused(dqn_handle *h, int32_t B, void *stream);
-int dqn_update_backward(dqn_handle *h, int32_t B, void *stream);   /* sample .. grads */
-int dqn_update_apply(dqn_handle *h, int32_t B, void *stream);      /* optimizer + PER write-back */
+int dqn_update_backward(dqn_handle *h, int32_t B, void *stream);   /* sample .. grads, + PER write-back */
+int dqn_update_apply(dqn_handle *h, int32_t B, void *stream);      /* optimizer on the (all-reduced) grads */
 
 /* compute_action (q_learning_functions.py:67-73) + Agent._policy (q_agent.py:137-141),
  * vectorised over n rows: greedy iff eps < U(0,1) else randint(0, A), Philox stream 2. */
@@ -168,6 +168,9 @@ int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
  * each iteration = env_steps vector env steps (train_frequency) followed by one Agent._step.
  * Single-GPU path (world_size == 1). */
 int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps, int32_t n_envs, int32_t B, void *stream);
+/* data-parallel form of one iteration: env_steps vector env steps + dqn_update_backward as ONE graph launch;
+ * follow with the gradient all-reduce and dqn_update_apply. */
+int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_envs, int32_t B, void *stream);
 
 /* Agent._update_target_model (q_agent.py:143-144) */
 int dqn_sync_target(dqn_handle *h, void *stream);

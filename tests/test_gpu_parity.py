@@ -363,7 +363,7 @@ def test_profile_hooks_and_error_paths(dq):
         e.profile_begin()
         e.update_backward(64); e.update_apply(64)
         prof = e.profile_end()
-    assert [k for k, _ in prof] == ["per_sample", "qnet_fwd_x3", "td_bwd_rows", "dw", "adam", "per_update"]
+    assert [k for k, _ in prof] == ["per_sample", "qnet_fwd_x3", "td_bwd_rows", "dw_perwrite", "per_top", "adam"]
     assert all(ms >= 0 for _, ms in prof)
     with pytest.raises(dq._lib.DqnError):
         e.update(65)                                           # > max_batch
@@ -407,5 +407,42 @@ def test_train_iters_one_graph_matches_oracle(dq):
     assert np.array_equal(host(e.buffer(dq._lib.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
     for x, y in zip((e.buffer(dq._lib.BUF_STATES).view(N, D), e.buffer(dq._lib.BUF_REWARDS)), (cr.arrays()[0], cr.arrays()[2])):
         assert np.array_equal(host(x), y)
+    assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    e.close()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_data_parallel_halves_match_oracle(dq, world):
+    """the N>1 step = dqn_actor_backward -> gradient all-reduce -> dqn_update_apply. With `world` identical ranks
+    the summed gradient is world x the local one and the optimizer divides by world: the result must equal
+    the single-learner oracle loop."""
+    import torch
+    dims = CFGS["cfg1"]
+    D = dims[0]
+    L_, n, B = 11, 64, 64
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=91, lr=1e-3, world_size=world)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, 512, 92, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    ct.add(cr.add(s, a, r, s2, d > 0)); e.replay_add(s, a, r, s2, d > 0)
+    P0 = rand_params(dims, 93)
+    e.set_params(P0); e.sync_target()
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 91, beta=0.4)
+    obs = np.random.default_rng(94).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
+    grad = e.buffer(dq._lib.BUF_GRAD)
+    ctr = 0
+    with torch.cuda.stream(e.stream):
+        for _ in range(4):
+            for _ in range(4):
+                ctr = lrn.actor_step(obs, 0.2, 0.05, ctr)
+            lrn.update(B)
+            e.actor_backward(4, B)
+            grad.mul_(float(world))                    # what a SUM all-reduce over `world` identical ranks leaves
+            e.update_apply(B)
+        e.stream.synchronize()
+    assert e.opt_count() == 4 and e.replay_size() == (cr.size, cr.rb.counter)
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
     assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
     e.close()
