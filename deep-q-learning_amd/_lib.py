@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("DQN_HIP_LIB", os.path.join(_HERE, "libdqn_hip.so"))  
 OPT_ADAM, OPT_ADAMW = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
+ENV_SYNTHETIC, ENV_CARTPOLE = 0, 1
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
  BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,
  BUF_ENV_ACTIONS) = range(17)
@@ -60,6 +61,8 @@ SIGNATURES = {
     "dqn_act": [_P, _P, _I32, _F, _U64, _U64, _P, _P],
     "dqn_sync_target": [_P, _P],
     "dqn_set_epsilon": [_P, _F, _P],
+    "dqn_env_config": [_P, _I32, _I32, _F],
+    "dqn_env_stats_host": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "dqn_env_reset": [_P, _P, _I32, _F, _P],
     "dqn_actor_step": [_P, _I32, _P],
     "dqn_train_iters": [_P, _I32, _I32, _I32, _I32, _P],

@@ -81,6 +81,7 @@ struct dqn_handle {
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
     float p_done = 0.01f;
+    int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
     bool profiling = false;
     std::vector<hipEvent_t> events; size_t ev_used = 0;
@@ -178,7 +179,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
-    add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp);
+    add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp); add(&h->env_t, Bp * 4);
     size_t total = 0;
     for (auto &it : items) total += align_up(it.bytes, 256);
     hipError_t e = hipMalloc(&h->arena, total);
@@ -552,6 +553,7 @@ static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st) {
     e.st = h->st; e.states = h->states; e.actions = h->actions; e.rewards = h->rewards; e.observations = h->observations;
     e.dones = h->dones; e.cap = h->cfg.capacity; e.tree = h->cfg.use_per ? h->tree : nullptr; e.Nt = h->Ntree; e.L = h->L;
     e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
+    e.kind = h->env_kind; e.max_steps = h->env_max_steps; e.env_t = h->env_t; e.term_reward = h->env_term_reward;
     arm(h);
     L_fwd(h, st, &p, 1, n_envs, &e);
     mark(h, st, "actor_step");
@@ -623,7 +625,28 @@ extern "C" int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, fl
     REQUIRE(h && obs, "null argument");
     REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch, "n_envs=%d exceeds max_batch=%d", n_envs, h->cfg.max_batch);
     h->p_done = p_done;
+    HIP_TRY(hipMemsetAsync(h->env_t, 0, (size_t)n_envs * 4, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(h->env_obs, obs, (size_t)n_envs * h->cfg.obs_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DQN_OK;
+}
+
+extern "C" int dqn_env_config(dqn_handle *h, int32_t kind, int32_t max_steps, float term_reward) {
+    REQUIRE(h, "null argument");
+    REQUIRE(kind == DQN_ENV_SYNTHETIC || kind == DQN_ENV_CARTPOLE, "unknown env kind %d", kind);
+    REQUIRE(kind != DQN_ENV_CARTPOLE || (h->cfg.obs_dim == 4 && h->cfg.num_actions == 2), "CartPole needs obs_dim 4, num_actions 2");
+    REQUIRE(max_steps >= 1, "max_steps must be >= 1");
+    h->env_kind = kind; h->env_max_steps = max_steps; h->env_term_reward = term_reward;
+    destroy_graphs(h);                                           // env parameters are baked into captured launches
+    return DQN_OK;
+}
+
+extern "C" int dqn_env_stats_host(dqn_handle *h, int64_t *episodes, int64_t *episode_steps) {
+    REQUIRE(h, "null argument");
+    DqnState s;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&s, h->st, sizeof(s), hipMemcpyDeviceToHost));
+    if (episodes) *episodes = (int64_t)s.ep_count;
+    if (episode_steps) *episode_steps = (int64_t)s.ep_steps;
     return DQN_OK;
 }
 

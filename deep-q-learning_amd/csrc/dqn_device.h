@@ -29,6 +29,8 @@ struct DqnState {
     float              pad0;
     unsigned int       arrive;         // last-block tickets
     unsigned int       pad;
+    unsigned long long ep_count;       // finished episodes of the device-resident envs (CartPole)
+    unsigned long long ep_steps;       // env steps (= return, reward 1 per step) summed over finished episodes
 };
 
 enum { DQN_STREAM_PER = 0, DQN_STREAM_UNIFORM = 1, DQN_STREAM_POLICY = 2, DQN_STREAM_ENV = 3 };

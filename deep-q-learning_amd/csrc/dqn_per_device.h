@@ -125,7 +125,70 @@ struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic e
     float *states; int32_t *actions; float *rewards; float *observations; uint8_t *dones;
     long long cap; float *tree; long long Nt; int L;
     float *env_obs; unsigned long long seed; float p_done; int n;
+    int kind;               // 0: synthetic transitions; 1: CartPole-v1 physics
+    int max_steps;          // episode truncation (q_agent.py:179-180)
+    int32_t *env_t;         // per-env step counter
+    float term_reward;      // CartPole: reward of the step that terminates the episode (gym: 1; see dqn_env_config)
 };
+
+// ---- CartPole-v1 (classic control; BASELINE.json configs[2]). Euler step of the published cart-pole equations in
+// f32 with one rounding per written operation and polynomial sin / cos (|theta| stays < 0.25 rad), so the CPU
+// restatement reproduces every state bit for bit. Auto-reset on termination / truncation: the stored transition
+// keeps the terminal next-state, the env continues from a fresh U(-0.05, 0.05)^4 state (Philox stream 3).
+__device__ __forceinline__ float cp_sin(float t) {            // t - t^3/6 + t^5/120 - t^7/5040
+    const float t2 = t * t;
+    float p = -1.98412701e-4f;
+    p = p * t2; p = p + 8.33333377e-3f;
+    p = p * t2; p = p + -0.166666672f;
+    p = p * t2; p = p + 1.0f;
+    return p * t;
+}
+__device__ __forceinline__ float cp_cos(float t) {            // 1 - t^2/2 + t^4/24 - t^6/720
+    const float t2 = t * t;
+    float p = -1.38888892e-3f;
+    p = p * t2; p = p + 4.16666679e-2f;
+    p = p * t2; p = p + -0.5f;
+    p = p * t2; p = p + 1.0f;
+    return p;
+}
+__device__ __forceinline__ bool cartpole_step(float (&s)[4], int action) {
+    const float force = action == 1 ? 10.0f : -10.0f;
+    const float ct = cp_cos(s[2]), sn = cp_sin(s[2]);
+    const float temp = __fdiv_rn(force + (0.05f * (s[3] * s[3])) * sn, 1.1f);
+    const float thetaacc = __fdiv_rn((9.8f * sn) - (ct * temp), 0.5f * (1.33333337f - __fdiv_rn(0.1f * (ct * ct), 1.1f)));
+    const float xacc = temp - __fdiv_rn((0.05f * thetaacc) * ct, 1.1f);
+    s[0] = s[0] + 0.02f * s[1];
+    s[1] = s[1] + 0.02f * xacc;
+    s[2] = s[2] + 0.02f * s[3];
+    s[3] = s[3] + 0.02f * thetaacc;
+    return s[0] < -2.4f || s[0] > 2.4f || s[2] < -0.20943951f || s[2] > 0.20943951f;
+}
+// one thread per env of [i0, i0+cnt): physics, ring row, episode bookkeeping, auto-reset
+__device__ __forceinline__ void cartpole_rows(int tr, int nthr, int i0, int cnt, unsigned long long c0, unsigned long long ec,
+                                              const EnvArgs &e, const int32_t *acts, int acts_base) {
+    for (int il = tr; il < cnt; il += nthr) {
+        const int i = i0 + il;
+        const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)e.cap);
+        float s[4];
+        for (int j = 0; j < 4; ++j) { s[j] = e.env_obs[(long long)i * 4 + j]; e.states[k * 4 + j] = s[j]; }
+        const int a = acts[i - acts_base];
+        const bool term = cartpole_step(s, a);
+        const int t = e.env_t[i] + 1;
+        const bool done = term || t >= e.max_steps;                      // q_agent.py:179-180
+        for (int j = 0; j < 4; ++j) e.observations[k * 4 + j] = s[j];
+        e.actions[k] = a; e.rewards[k] = term ? e.term_reward : 1.0f; e.dones[k] = done ? 1 : 0;
+        if (done) {
+            atomicAdd(&e.st->ep_count, 1ull);
+            atomicAdd(&e.st->ep_steps, (unsigned long long)t);
+            const u32x4 o = philox_draw(e.seed, ec, (uint32_t)i, DQN_STREAM_ENV);
+            s[0] = (u01(o.x) * 0.1f) - 0.05f; s[1] = (u01(o.y) * 0.1f) - 0.05f;
+            s[2] = (u01(o.z) * 0.1f) - 0.05f; s[3] = (u01(o.w) * 0.1f) - 0.05f;
+        }
+        e.env_t[i] = done ? 0 : t;
+        for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = s[j];
+    }
+}
+
 
 // a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3) -- exactly reproducible on the CPU
 __device__ __forceinline__ float ih_normal(const u32x4 o) {
@@ -136,6 +199,7 @@ __device__ __forceinline__ float ih_normal(const u32x4 o) {
 // (env, element): elements 0..D-1 are the next observation, element D is (reward, done). Thread `tr` of `nthr`.
 __device__ __forceinline__ void env_rows(int tr, int nthr, int i0, int cnt, unsigned long long c0, unsigned long long ec,
                                          const EnvArgs &e, int D, const int32_t *acts, int acts_base) {
+    if (e.kind == 1) { cartpole_rows(tr, nthr, i0, cnt, c0, ec, e, acts, acts_base); return; }
     for (int t = tr; t < cnt * (D + 1); t += nthr) {
         const int il = t / (D + 1), el = t - il * (D + 1), i = i0 + il;
         const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)e.cap);

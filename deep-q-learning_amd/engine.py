@@ -312,6 +312,16 @@ class Engine:
         L.check(self.lib.dqn_env_reset(self.h, _ptr(obs), obs.shape[0], float(p_done), self._s()))
         self.n_envs = obs.shape[0]
 
+    def env_config(self, kind="synthetic", max_steps=500, term_reward=1.0):
+        L.check(self.lib.dqn_env_config(self.h, {"synthetic": L.ENV_SYNTHETIC, "cartpole": L.ENV_CARTPOLE}[kind],
+                                        int(max_steps), float(term_reward)))
+
+    def env_stats(self):
+        """(finished episodes, summed episode length) of the device-resident envs; synchronises"""
+        ep, st = C.c_int64(), C.c_int64()
+        L.check(self.lib.dqn_env_stats_host(self.h, C.byref(ep), C.byref(st)))
+        return ep.value, st.value
+
     def actor_step(self, stream=None):
         """one vector env step (q_agent.py:176-183) on the device-resident synthetic envs"""
         L.check(self.lib.dqn_actor_step(self.h, self.n_envs, self._s(stream)))

@@ -46,6 +46,8 @@ typedef enum {                                                              /* d
     DQN_BUF_ENV_OBS = 15, DQN_BUF_ENV_ACTIONS = 16
 } dqn_buffer_id;
 
+typedef enum { DQN_ENV_SYNTHETIC = 0, DQN_ENV_CARTPOLE = 1 } dqn_env_kind;   /* device-resident vector envs */
+
 typedef struct dqn_handle dqn_handle;
 
 /* Mirrors the constants of Test/lunar_lander.py:23-48 plus the net dims of
@@ -162,6 +164,14 @@ int dqn_act(dqn_handle *h, const float *s, int32_t n, float epsilon, uint64_t se
  * replay.add -> state = observation. Graph-replayed; epsilon and the step counter live on
  * the device. dqn_env_reset uploads the initial observations [n_envs, D]. */
 int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream);
+/* kind of the device-resident envs: DQN_ENV_SYNTHETIC (default) or DQN_ENV_CARTPOLE (CartPole-v1 physics, obs 4,
+ * actions 2, reward 1 per step, truncation at max_steps as q_agent.py:179-180, auto-reset). term_reward is the
+ * reward of the step that TERMINATES an episode (gym: 1). NOTE: the reference's target rule (q_learning_functions.py
+ * :58, kept verbatim) makes the terminal target q + r, so a positive terminal reward inflates Q at failures; pass a
+ * negative term_reward (e.g. -1) to make CartPole learnable under that rule. dqn_env_stats_host returns the number
+ * of finished episodes and their summed length (synchronises). */
+int dqn_env_config(dqn_handle *h, int32_t kind, int32_t max_steps, float term_reward);
+int dqn_env_stats_host(dqn_handle *h, int64_t *episodes, int64_t *episode_steps);
 int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream);
 int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
 /* the reference's inner loop (q_agent.py:174-187) for n_iters iterations as ONE hipGraph launch:

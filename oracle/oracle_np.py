@@ -377,3 +377,42 @@ def synth_env(n, D, seed, env_ctr, p_done):
            * f(1.73205078)).astype(f)
     rew = np.where(done, np.where(o[:, D, 1] & np.uint32(1), f(100.0), f(-100.0)), rew).astype(f)
     return obs_next.astype(f), rew, done.astype(np.uint8)
+
+
+# ------------------------------------------------------------------ CartPole-v1
+def _cp_poly(t2, coefs):
+    p = np.full_like(t2, np.float32(coefs[0]))
+    for c in coefs[1:]:
+        p = (p * t2).astype(np.float32)
+        p = (p + np.float32(c)).astype(np.float32)
+    return p
+
+
+def cartpole_step(s, a):
+    """One Euler step of CartPole-v1 for n envs (classic-control cart-pole equations; BASELINE.json configs[2]),
+    f32, one rounding per operation, polynomial sin / cos. s: (n,4) f32, a: (n,) {0,1}.
+    Returns (next state, terminated)."""
+    f = np.float32
+    s = np.asarray(s, f).copy()
+    x, xd, th, thd = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
+    force = np.where(np.asarray(a) == 1, f(10.0), f(-10.0)).astype(f)
+    t2 = (th * th).astype(f)
+    sn = (_cp_poly(t2, (-1.98412701e-4, 8.33333377e-3, -0.166666672, 1.0)) * th).astype(f)
+    ct = _cp_poly(t2, (-1.38888892e-3, 4.16666679e-2, -0.5, 1.0))
+    temp = ((force + ((f(0.05) * (thd * thd).astype(f)).astype(f) * sn).astype(f)).astype(f) / f(1.1)).astype(f)
+    den = (f(0.5) * (f(1.33333337) - ((f(0.1) * (ct * ct).astype(f)).astype(f) / f(1.1)).astype(f)).astype(f)).astype(f)
+    thacc = (((f(9.8) * sn).astype(f) - (ct * temp).astype(f)).astype(f) / den).astype(f)
+    xacc = (temp - (((f(0.05) * thacc).astype(f) * ct).astype(f) / f(1.1)).astype(f)).astype(f)
+    nx = (x + (f(0.02) * xd).astype(f)).astype(f)
+    nxd = (xd + (f(0.02) * xacc).astype(f)).astype(f)
+    nth = (th + (f(0.02) * thd).astype(f)).astype(f)
+    nthd = (thd + (f(0.02) * thacc).astype(f)).astype(f)
+    out = np.stack([nx, nxd, nth, nthd], axis=1).astype(f)
+    term = (nx < f(-2.4)) | (nx > f(2.4)) | (nth < f(-0.20943951)) | (nth > f(0.20943951))
+    return out, term
+
+
+def cartpole_reset_states(n, seed, env_ctr):
+    """fresh U(-0.05, 0.05)^4 states for all n envs at vector step env_ctr (only the done envs use theirs)"""
+    o = philox_draw(seed, env_ctr, n, STREAM_ENV)
+    return ((u01(o) * np.float32(0.1)).astype(np.float32) - np.float32(0.05)).astype(np.float32)
