@@ -53,7 +53,7 @@ def algorithmic_cost(name, L, n_params):
         return "hbm", 28 * n_params
     if name == "env_step_add":        # synthetic transition + ring insert + PER leaf-range insert
         return "hbm", ((4 * D + 5) + 2 * (8 * D + 9) + (8 * L + 4)) * N_ENVS
-    if name == "qnet_fwd_x3":
+    if name in ("qnet_fwd_x3", "sample_fwd_x3"):     # three forwards (+ the fused PER sampling of their rows)
         return "mfma", 3 * F * B
     if name in ("act_fwd_policy", "actor_step"):      # forward + policy + env step + ring/tree insert, one launch
         return "mfma", F * N_ENVS
@@ -69,7 +69,7 @@ def algorithmic_cost(name, L, n_params):
 PMC_KEYS = {   # bench kernel label -> (kernel name in profiles/*_pmc.json, FETCH_SIZE correction)
     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads; other widths
     # are uncalibrated and taken as reported. The forward kernel appears once per grid size (actor vs 3-pass launch).
-    "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0),
+    "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3": ("k_qnet_fwd:max", 2.0),
     "td_bwd_rows": ("k_bwd_rows", 2.0), "dw_adam_perwrite": ("k_dw", 2.0), "dw_perwrite": ("k_dw", 2.0), "dw_adam": ("k_dw", 2.0), "dw": ("k_dw", 2.0),
     "per_sample": ("k_per_sample", 1.0), "per_top": ("k_per_top", 1.0),
 }
@@ -326,7 +326,7 @@ def main():
                               "frac": ach / peak}
         # dominant KERNEL = largest time share per step. k_qnet_fwd is launched in two shapes (4 actor launches of
         # 256 rows + 1 three-pass launch of 3x1024 rows): its roofline entry aggregates all five launches of a step.
-        groups = {"k_qnet_fwd": [k for k in ("actor_step", "qnet_fwd_x3") if k in per_step]}
+        groups = {"k_qnet_fwd": [k for k in ("actor_step", "qnet_fwd_x3", "sample_fwd_x3") if k in per_step]}
         for k in per_step:
             if k not in groups["k_qnet_fwd"]:
                 groups[k] = [k]

@@ -100,8 +100,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pack) {
     if (h->bf16) launch_pack_bf16(s, h->m, params, pack); else launch_pack(s, h->m, params, pack);
 }
-static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env); else launch_qnet_fwd(s, h->m, p, n, B, env);
+static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr,
+                  const SampleArgs *smp = nullptr) {
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp); else launch_qnet_fwd(s, h->m, p, n, B, env, smp);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -485,23 +486,20 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
 // fuse_adam: optimizer applied in the dW epilogue (single GPU). fork: run the PER write-back on a
 // parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
 static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fuse_pw = false) {
-    // q_agent.py:147-153 sample_batch
+    // q_agent.py:147-153 sample_batch + :159-165 compute_q_targets' three forwards, ONE launch: every forward
+    // workgroup draws its own 16 rows (stratified PER descent or uniform Philox index) and reads them from the ring
+    SampleArgs sm{};
+    sm.st = h->st; sm.tree = h->cfg.use_per ? h->tree : nullptr; sm.N = h->Ntree; sm.L = h->L;
+    sm.states = h->states; sm.observations = h->observations; sm.rewards = h->rewards; sm.actions = h->actions;
+    sm.dones = h->dones; sm.seed = h->cfg.seed;
+    sm.idx = h->bidx; sm.a = h->ba; sm.r = h->br; sm.w_raw = h->bw_raw; sm.d = h->bd;
+    FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, nullptr, h->q, nullptr, true),
+                     make_pass(h, DQN_NET_ONLINE, nullptr, h->nq, nullptr, false),
+                     make_pass(h, DQN_NET_TARGET, nullptr, h->nt, nullptr, false) };
+    p[0].src = 1; p[1].src = 2; p[2].src = 2;
     arm(h);
-    if (h->cfg.use_per)
-        launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
-                          h->dones, h->cfg.obs_dim, B, 0.f, h->cfg.seed, 0, 1, h->bs, h->ba, h->br, h->bs2, h->bd,
-                          h->bidx, h->bw_raw);
-    else
-        launch_sample_uniform(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones,
-                              h->cfg.obs_dim, B, h->cfg.seed, 0, 1, nullptr, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx);
-    mark(h, st, h->cfg.use_per ? "per_sample" : "uniform_sample");
-    // q_agent.py:159-165 compute_q_targets: three forwards
-    FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, true),
-                     make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),
-                     make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false) };
-    arm(h);
-    L_fwd(h, st, p, 3, B);
-    mark(h, st, "qnet_fwd_x3");
+    L_fwd(h, st, p, 3, B, nullptr, &sm);
+    mark(h, st, "sample_fwd_x3");
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
     BwdArgs g{};
     g.q = h->q; g.nq = h->nq; g.nt = h->nt; g.a = h->ba; g.r = h->br; g.d_u8 = h->bd;

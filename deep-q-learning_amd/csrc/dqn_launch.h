@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 
 struct EnvArgs;   // dqn_per_device.h
+struct SampleArgs;
 
 // Kernel launch used by the hot-path launchers. In profiling mode (dqn_profile_begin) the API arms a pair of
 // events before each launch; the launch is then issued with hipExtLaunchKernelGGL so that the two events carry the
@@ -42,6 +43,7 @@ struct FwdPass {
     float *q;              // [B, A] out (may be NULL)
     float *feat;           // [B, H2] row-major out (may be NULL)
     float *px, *ph1, *ph2; // batch-major packed stashes for backward (may be NULL)
+    int src;               // with fused sampling: 1 = ring states of the sampled rows, 2 = their observations
     // optional fused epsilon-greedy policy (q_agent.py:137-141) on the rows of this pass
     int32_t *act_out;            // [B] or NULL
     const DqnState *act_state;   // non-NULL: epsilon / counter from the device state
@@ -72,7 +74,8 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 };
 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
-void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr);
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
+                     const SampleArgs *smp = nullptr);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
                const float *r, const float *d, const float *isw, float gamma, int B, int A,
                float *targets, float *td, float *dq, float *loss, float *scratch);
@@ -119,7 +122,8 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 // ----- bf16 MFMA variants (dqn_net_bf16.hip); pointer fields typed float* carry bf16 data -------------
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
-void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr);
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
+                          const SampleArgs *smp = nullptr);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

@@ -218,7 +218,7 @@ struct FwdPasses { FwdPass p[3]; };
 
 template <int TN1, int TN2>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env) {
+k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ACTOR_PROLOGUE(lds)
     const FwdPass ps = passes.p[blockIdx.y];
@@ -233,12 +233,18 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env) {
     // Vector-memory returns are in order, so the order of issue is the order of arrival: the 16 input
     // rows first, then layer-1 weights + biases, then all of layer 2 and the heads (they stream in
     // while layer 1 runs; nothing below waits for more than it needs).
-    float xv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int t = tid + 256 * u;
+    const bool sampling = smp.st != nullptr;
+    int *lidx = reinterpret_cast<int *>(lh + 256 + 16);            // leaves of this tile's rows (sampling mode)
+    const float *ring = sampling ? (ps.src == 1 ? smp.states : smp.observations) : nullptr;
+    auto xload = [&](int t) -> float {
         const int rl = t / K1, c = t - rl * K1;
-        xv[u] = (t < 16 * K1 && row0 + rl < B && c < m.D) ? ps.x[(long long)(row0 + rl) * m.D + c] : 0.0f;
+        if (!(t < 16 * K1 && row0 + rl < B && c < m.D)) return 0.0f;
+        return sampling ? ring[(long long)lidx[rl] * m.D + c] : ps.x[(long long)(row0 + rl) * m.D + c];
+    };
+    float xv[4];
+    if (!sampling) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
     }
     MmaLayer<TN1, 2, true> L1; MmaLayer<TN2, 16, false> L2; MmaLayer<1, 16, false> LH;
     L1.start(ps.pack + m.p_w1, m.KQ1, m.H1 / 16, wave, lane);
@@ -255,6 +261,18 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env) {
     L2.init(ps.pack + m.p_w2, m.H1 / 16, m.H2 / 16, wave, lane);
     L2.template load_range<0, 6>();                          // the first AHEAD k-blocks; the rest interleave with the MFMAs
     if (wave == 0) LH.init(ps.pack + m.p_wh, m.H2 / 16, 1, 0, lane);
+    if (sampling) {
+        // the weight requests above are in flight; now the dependent tree descent, then the gathered rows
+        if (smp.tree) {
+            float *lsub = reinterpret_cast<float *>(lidx + 16);
+            sample_tile_coop(smp, row0, B, tid, blockIdx.y == 0, lidx, lsub, lsub + 512);     // ends with a barrier
+        } else {
+            if (tid < 16) sample_tile(smp, row0, B, tid, blockIdx.y == 0, lidx);
+            LDS_BARRIER();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
+    }
 
     // stage the 16 input rows (zero-padded) in A-operand order
 #pragma unroll
@@ -268,8 +286,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env) {
     }
     for (int t = tid + 1024; t < 16 * K1; t += 256) {            // obs_dim > 64 only
         const int rl = t / K1, c = t - rl * K1;
-        float v = 0.0f;
-        if (row0 + rl < B && c < m.D) v = ps.x[(long long)(row0 + rl) * m.D + c];
+        const float v = xload(t);
         lx[rl * sx + (c & ~15) + perm16(c & 15)] = v;
         if (ps.px) ps.px[pidx(KQb, row0 + rl, c)] = v;
     }
@@ -365,16 +382,18 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env) {
 
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
 
-void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env) {
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
+                     const SampleArgs *smp) {
     FwdPasses ps{};
     for (int i = 0; i < npass; ++i) ps.p[i] = passes[i];
     const EnvArgs ea = env ? *env : EnvArgs{};
+    const SampleArgs sa = smp ? *smp : SampleArgs{};
     const int extra = (env && env->tree) ? 1 : 0;                       // surplus workgroup: leaf-range insert
     const dim3 grid((B + 15) / 16 + extra, npass), block(256);
-    size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 16);
+    size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 32 + 528);
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2>), grid, block, lds, s, m, ps, B, ea); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2>), grid, block, lds, s, m, ps, B, ea, sa); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
@@ -649,8 +668,10 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     __shared__ float redb[4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if ((int)blockIdx.x >= tiles) {
-        // surplus workgroups: the PER priority write-back of this batch (independent of the weight
-        // gradients; sharing the launch hides it behind the dW tiles on other CUs)
+        // surplus workgroups: the PER priority write-back of this batch (independent of the weight gradients; sharing
+        // the launch hides it behind the dW tiles on other CUs). The dense top of the tree is rebuilt by the next
+        // launch (k_per_top): doing it here behind a release -> counter -> acquire hand-off was measured slower
+        // (21 us vs 10.6 + 5.4 us), as the guide predicts for an all-to-all seam.
         if (wave == 0)
             per_write_sorted_wave(st, pw.tree, pw.N, pw.L, pw.idx, pw.td_abs, pw.B, 1, pw.alpha, pw.eps, (int)blockIdx.x - tiles);
         return;

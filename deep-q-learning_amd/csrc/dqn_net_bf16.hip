@@ -152,7 +152,7 @@ struct FwdPasses16 { FwdPass p[3]; };
 
 template <int TN1, int TN2>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env) {
+k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, SampleArgs smp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ACTOR_PROLOGUE(smem)
     const FwdPass ps = passes.p[blockIdx.y];
@@ -167,12 +167,18 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env) {
     float *lh = reinterpret_cast<float *>(l2 + 16 * s2);
 
     // order of issue = order of arrival: input rows, layer 1, biases, layer 2, heads
-    float xv[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int t = tid + 256 * u;
+    const bool sampling = smp.st != nullptr;
+    int *lidx = reinterpret_cast<int *>(lh + 256 + 16);
+    const float *ring = sampling ? (ps.src == 1 ? smp.states : smp.observations) : nullptr;
+    auto xload = [&](int t) -> float {
         const int rl = t / K1, c = t - rl * K1;
-        xv[u] = (t < 16 * K1 && row0 + rl < B && c < m.D) ? ps.x[(long long)(row0 + rl) * m.D + c] : 0.0f;
+        if (!(t < 16 * K1 && row0 + rl < B && c < m.D)) return 0.0f;
+        return sampling ? ring[(long long)lidx[rl] * m.D + c] : ps.x[(long long)(row0 + rl) * m.D + c];
+    };
+    float xv[2];
+    if (!sampling) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xv[u] = xload(tid + 256 * u);
     }
     MmaLayer16<TN1, 8> L1; MmaLayer16<TN2, 8> L2; MmaLayer16<1, 8> LH;
     L1.start(pack + d.p_w1, d.KQ1, m.H1 / 16, wave, lane);
@@ -188,6 +194,17 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env) {
     }
     L2.start(pack + d.p_w2, d.KQ2, m.H2 / 16, wave, lane);
     if (wave == 0) LH.start(pack + d.p_wh, d.KQH, 1, 0, lane);
+    if (sampling) {
+        if (smp.tree) {
+            float *lsub = reinterpret_cast<float *>(lidx + 16);
+            sample_tile_coop(smp, row0, B, tid, blockIdx.y == 0, lidx, lsub, lsub + 512);     // ends with a barrier
+        } else {
+            if (tid < 16) sample_tile(smp, row0, B, tid, blockIdx.y == 0, lidx);
+            LDS_BARRIER();
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xv[u] = xload(tid + 256 * u);
+    }
 
     // zero the k-padding columns of the hidden activations (hidden % 32 == 16 only)
     for (int t = tid; t < 16 * (K2 - m.H1); t += 256) l1[(t / (K2 - m.H1)) * s1 + m.H1 + t % (K2 - m.H1)] = (__bf16)0.0f;
@@ -204,8 +221,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env) {
     }
     for (int t = tid + 512; t < 16 * K1; t += 256) {             // obs_dim > 32 only
         const int rl = t / K1, c = t - rl * K1;
-        float v = 0.0f;
-        if (row0 + rl < B && c < m.D) v = ps.x[(long long)(row0 + rl) * m.D + c];
+        const float v = xload(t);
         lx[rl * sx + c] = (__bf16)v;
         if (px && c < m.KQ1 * 16) px[pidx16(KQb, row0 + rl, c)] = (__bf16)v;
     }
@@ -291,18 +307,20 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env) {
 // tiles are launched in pairs so that every 32-row k-block of the batch-major stashes is fully written
 static inline int tiles16(int B) { return 2 * ((B + 31) / 32); }
 
-void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env) {
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
+                          const SampleArgs *smp) {
     FwdPasses16 ps{};
     bool stash = false;
     for (int i = 0; i < npass; ++i) { ps.p[i] = passes[i]; stash |= passes[i].px != nullptr; }
     const Dims16 d = make_dims16(m);
     const EnvArgs ea = env ? *env : EnvArgs{};
+    const SampleArgs sa = smp ? *smp : SampleArgs{};
     const int extra = (env && env->tree) ? 1 : 0;
     const dim3 grid((stash ? tiles16(B) : (B + 15) / 16) + extra, npass), block(256);
-    size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 16);
+    size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 32 + 528);
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2>), grid, block, lds, s, m, d, ps, B, ea); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2>), grid, block, lds, s, m, d, ps, B, ea, sa); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
@@ -458,6 +476,10 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
     __shared__ float redb[4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if ((int)blockIdx.x >= tiles) {
+        // surplus workgroups: the PER priority write-back of this batch (independent of the weight gradients; sharing
+        // the launch hides it behind the dW tiles on other CUs). The dense top of the tree is rebuilt by the next
+        // launch (k_per_top): doing it here behind a release -> counter -> acquire hand-off was measured slower
+        // (21 us vs 10.6 + 5.4 us), as the guide predicts for an all-to-all seam.
         if (wave == 0)
             per_write_sorted_wave(st, pw.tree, pw.N, pw.L, pw.idx, pw.td_abs, pw.B, 1, pw.alpha, pw.eps, (int)blockIdx.x - tiles);
         return;

@@ -331,3 +331,110 @@ __device__ __forceinline__ void actor_commit(const EnvArgs &e, unsigned long lon
         }
     }
 }
+
+// ------------------------------------------------------------ sampling fused into the forward launch
+// q_agent.py:147-153 (sample_batch) for the fused update: every forward workgroup draws the 16 batch rows it is about
+// to push through the network (same Philox draw / stratified descent / clamp / raw IS weight as k_per_sample, so
+// the indices are identical), reads those rows straight from the ring, and -- pass 0 only -- publishes idx, a, r, d,
+// w_raw and the batch max weight for the backward kernel. The dependent 20-load descent overlaps the weight stream.
+struct SampleArgs {
+    DqnState *st;                        // NULL => rows come from FwdPass.x
+    const float *tree; long long N; int L;   // tree == NULL => uniform sampling (Philox stream 1)
+    const float *states, *observations, *rewards; const int32_t *actions; const uint8_t *dones;
+    unsigned long long seed;
+    int32_t *idx, *a; float *r, *w_raw; uint8_t *d;
+};
+
+__device__ __forceinline__ long long sample_leaf(const SampleArgs &s, int k, int B, float *w_out) {
+    const unsigned long long ctr = s.st->sample_ctr;
+    const long long size = s.st->size;
+    if (!s.tree) {                                                           // replay_buffer.py:77
+        const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)k, DQN_STREAM_UNIFORM);
+        *w_out = 1.0f;
+        return (long long)(((unsigned long long)o.x * (unsigned long long)size) >> 32);
+    }
+    const float beta = s.st->beta;
+    const float total = s.tree[1];
+    const float seg = __fdiv_rn(total, (float)B);
+    const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)k, DQN_STREAM_PER);
+    float u = ((float)k + u01(o.x)) * seg;
+    long long node = 1;
+    for (int lvl = 0; lvl < s.L; ++lvl) {
+        const float l = s.tree[2 * node];
+        if (u < l) { node = 2 * node; }
+        else { u = u - l; node = 2 * node + 1; }
+    }
+    long long leaf = node - s.N;
+    if (leaf >= size) leaf = size - 1;
+    *w_out = pow_det(__fdiv_rn((float)size * s.tree[s.N + leaf], total), -beta);
+    return leaf;
+}
+
+// lanes 0..15 of wave 0: draw row row0+lane, leave the leaf in lidx[lane]; pass 0 publishes the batch fields
+__device__ __forceinline__ void sample_tile(const SampleArgs &s, int row0, int B, int lane16, bool publish, int *lidx) {
+    const int k = row0 + lane16, kk = k < B ? k : B - 1;
+    float w;
+    const long long leaf = sample_leaf(s, kk, B, &w);
+    lidx[lane16] = (int)leaf;
+    if (publish) {
+        if (k < B) {
+            s.idx[k] = (int32_t)leaf; s.w_raw[k] = w;
+            s.a[k] = s.actions[leaf]; s.r[k] = s.rewards[leaf]; s.d[k] = s.dones[leaf];
+        }
+        float mx = k < B ? w : 0.0f;
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane16 == 0 && s.tree) atomicMax(reinterpret_cast<unsigned int *>(&s.st->wmax), __float_as_uint(mx));
+    }
+}
+
+// Cooperative form of sample_tile for a 256-thread workgroup: 16 lanes per batch row. Per round trip the group
+// fetches the whole 4-level subtree below its current node (2+4+8+16 = 30 nodes, contiguous per level) into LDS and
+// walks it there -- 5 dependent memory latencies for L = 20 instead of 20. Same compares / subtractions in the same
+// order as the scalar descent, hence the same leaf. lsub: 16*32 floats, lw: 16 floats.
+__device__ __forceinline__ void sample_tile_coop(const SampleArgs &s, int row0, int B, int tid, bool publish,
+                                                 int *lidx, float *lsub, float *lw) {
+    const int g = tid >> 4, j = tid & 15;
+    const int k = row0 + g, kk = k < B ? k : B - 1;
+    const unsigned long long ctr = s.st->sample_ctr;
+    const long long size = s.st->size;
+    const float beta = s.st->beta;
+    const float total = s.tree[1];
+    const float seg = __fdiv_rn(total, (float)B);
+    const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
+    float u = ((float)kk + u01(o.x)) * seg;
+    long long cur = 1;
+    float *sub = lsub + g * 32;
+    for (int done = 0; done < s.L; done += 4) {
+        const int nl = s.L - done < 4 ? s.L - done : 4;
+        const int cnt = (2 << nl) - 2;
+        for (int f = j; f < cnt; f += 16) {
+            const int t = 31 - __clz(f + 2), i = f + 2 - (1 << t);        // flattened index -> (relative depth t, position i)
+            sub[f] = s.tree[(cur << t) + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the group is inside one wave: LDS program order
+        int p = 0;
+        for (int t = 1; t <= nl; ++t) {
+            const float l = sub[(1 << t) - 2 + 2 * p];
+            if (u < l) { p = 2 * p; }
+            else { u = u - l; p = 2 * p + 1; }
+        }
+        cur = (cur << nl) + p;
+    }
+    long long leaf = cur - s.N;
+    if (leaf >= size) leaf = size - 1;
+    if (j == 0) {
+        const float w = pow_det(__fdiv_rn((float)size * s.tree[s.N + leaf], total), -beta);
+        lidx[g] = (int)leaf;
+        lw[g] = k < B ? w : 0.0f;
+        if (publish && k < B) {
+            s.idx[k] = (int32_t)leaf; s.w_raw[k] = w;
+            s.a[k] = s.actions[leaf]; s.r[k] = s.rewards[leaf]; s.d[k] = s.dones[leaf];
+        }
+    }
+    LDS_BARRIER();
+    if (publish && tid == 0) {
+        float mx = 0.0f;
+        for (int q = 0; q < 16; ++q) mx = fmaxf(mx, lw[q]);
+        atomicMax(reinterpret_cast<unsigned int *>(&s.st->wmax), __float_as_uint(mx));
+    }
+}

@@ -363,7 +363,7 @@ def test_profile_hooks_and_error_paths(dq):
         e.profile_begin()
         e.update_backward(64); e.update_apply(64)
         prof = e.profile_end()
-    assert [k for k, _ in prof] == ["per_sample", "qnet_fwd_x3", "td_bwd_rows", "dw_perwrite", "per_top", "adam"]
+    assert [k for k, _ in prof] == ["sample_fwd_x3", "td_bwd_rows", "dw_perwrite", "per_top", "adam"]
     assert all(ms >= 0 for _, ms in prof)
     with pytest.raises(dq._lib.DqnError):
         e.update(65)                                           # > max_batch
@@ -445,4 +445,98 @@ def test_data_parallel_halves_match_oracle(dq, world):
     assert e.opt_count() == 4 and e.replay_size() == (cr.size, cr.rb.counter)
     assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
     assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    e.close()
+
+
+def test_native_rccl_world1_and_capture(dq):
+    """the C ABI's own RCCL path (dqn_comm_unique_id / dqn_comm_init / dqn_allreduce_grads, librccl via dlopen) with a
+    one-rank communicator: the all-reduce must leave the gradient unchanged, eagerly and inside a captured graph"""
+    import ctypes as C
+    import torch
+    dims = CFGS["cfg1"]
+    e = mk(dq, dims, max_batch=64)
+    L = dq._lib
+    uid = (C.c_char * 128)()
+    L.check(e.lib.dqn_comm_unique_id(uid))
+    L.check(e.lib.dqn_comm_init(e.h, uid, 0, 1))
+    g = np.random.default_rng(0).standard_normal(e.param_count).astype(np.float32)
+    e.set_params(g, L.BUF_GRAD)
+    with torch.cuda.stream(e.stream):
+        L.check(e.lib.dqn_allreduce_grads(e.h, e._s()))
+        e.stream.synchronize()
+        assert np.array_equal(e.get_params(L.BUF_GRAD, host=True), g)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=e.stream):
+            L.check(e.lib.dqn_allreduce_grads(e.h, e._s()))
+        graph.replay(); graph.replay()
+        e.stream.synchronize()
+    assert np.array_equal(e.get_params(L.BUF_GRAD, host=True), g)
+    e.close()
+
+
+def test_cfg3_full_size_loop(dq):
+    """BASELINE configs[2] at full size: CartPole shape (obs 4, act 2, 2x64 net), 4096 vectorised envs, PER batch 8192.
+    Two iterations of (1 vector env step + 1 update) against the oracle, then size-independent invariants."""
+    import torch
+    dims = CFGS["cfg3"]
+    D, n, B, L_ = 4, 4096, 8192, 16
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=21, lr=1e-3)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, 30000, 22, terminal_frac=0.05)
+    r = np.clip(r, -2, 2)
+    for k in range(0, 30000, 3000):
+        sl = slice(k, k + 3000)
+        ct.add(cr.add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)); e.replay_add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)
+    P0 = rand_params(dims, 23)
+    e.set_params(P0); e.sync_target()
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 21, beta=0.4)
+    obs = np.random.default_rng(24).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.02); e.set_epsilon(0.1)
+    ctr = 0
+    for _ in range(2):
+        ctr = lrn.actor_step(obs, 0.1, 0.02, ctr)
+        lrn.update(B)
+    with torch.cuda.stream(e.stream):
+        e.train_iters(2, 1, B)
+        e.stream.synchronize()
+    assert e.replay_size() == (cr.size, cr.rb.counter) and e.opt_count() == 2
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
+    assert np.array_equal(host(e.buffer(dq._lib.BUF_STATES).view(N, D)), cr.arrays()[0])
+    t = host(e.buffer(dq._lib.BUF_TREE))
+    k = np.arange(1, N)
+    assert np.array_equal(t[k], t[2 * k] + t[2 * k + 1])                 # every parent = left + right, whole tree
+    assert np.allclose(t, ct.tree, rtol=1e-4, atol=1e-6)
+    idx = host(e.buffer(dq._lib.BUF_BATCH_IDX, torch.int32))[:B]
+    assert np.all(np.diff(idx) >= 0) and idx.max() < cr.size              # stratified => sorted, clamped
+    e.close()
+
+
+def test_tree_invariant_under_replay_stress(dq):
+    """400 graph-replayed updates + 1600 vector env steps at the bench configuration (write-back waves riding in the dW
+    launch, top rebuilt by k_per_top, leaf-range inserts by the actor launches): `parent = left + right` must hold for
+    the whole 2^21-node tree at every check."""
+    import torch
+    dims = CFGS["cfg2"]
+    L_, B = 20, 1024
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=5)
+    e.set_params(rand_params(dims, 1)); e.sync_target()
+    gen = torch.Generator(device=e.device); gen.manual_seed(0)
+    for k in range(0, N, 1 << 16):
+        n = 1 << 16
+        e.replay_add(torch.randn(n, 8, device=e.device, generator=gen), torch.randint(0, 4, (n,), device=e.device, generator=gen, dtype=torch.int32),
+                     torch.randn(n, device=e.device, generator=gen), torch.randn(n, 8, device=e.device, generator=gen),
+                     torch.rand(n, device=e.device, generator=gen) < 0.01)
+    e.env_reset(torch.randn(256, 8, device=e.device, generator=gen)); e.set_epsilon(0.15)
+    k = torch.arange(1, N, device=e.device)
+    with torch.cuda.stream(e.stream):
+        for rep in range(40):
+            e.train_iters(10, 4, B)
+            if rep % 4 == 3:
+                e.stream.synchronize()
+                t = e.buffer(dq._lib.BUF_TREE)
+                bad = (t[k] != t[2 * k] + t[2 * k + 1]).nonzero()
+                assert bad.numel() == 0, (rep, bad[:8].flatten().tolist())
+    assert e.opt_count() == 400
     e.close()
