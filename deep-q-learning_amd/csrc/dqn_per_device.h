@@ -129,6 +129,7 @@ struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic e
     int max_steps;          // episode truncation (q_agent.py:179-180)
     int32_t *env_t;         // per-env step counter
     float term_reward;      // CartPole: reward of the step that terminates the episode (gym: 1; see dqn_env_config)
+    int rebuild_top;        // the surplus tree workgroup first rebuilds the dense top of the tree (deferred k_per_top)
 };
 
 // ---- CartPole-v1 (classic control; BASELINE.json configs[2]). Euler step of the published cart-pole equations in
@@ -308,9 +309,39 @@ __device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int 
     }
 }
 
+// dense top of the tree, whole workgroup: depth TOP-1 from the depth-TOP pairs in HBM, the levels above out of an
+// LDS image of 2^TOP floats (same arithmetic as k_per_top). Ends with a barrier.
+__device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int TOP = L < PW_TOP ? L : PW_TOP;
+    if (TOP == 0) return;
+    const int h = 1 << (TOP - 1);
+    for (int j = tid; j < h; j += nt) {
+        const float2 c = *reinterpret_cast<const float2 *>(tree + 2 * (h + j));
+        const float v = c.x + c.y;
+        top[h + j] = v;
+        tree[h + j] = v;
+    }
+    __syncthreads();
+    for (int d = TOP - 2; d >= 0; --d) {
+        const int cnt = 1 << d;
+        for (int j = tid; j < cnt; j += nt) {
+            const int p = cnt + j;
+            const float v = top[2 * p] + top[2 * p + 1];
+            top[p] = v;
+            tree[p] = v;
+        }
+        LDS_BARRIER();
+    }
+    __syncthreads();                                         // drain this workgroup's tree stores before it re-reads them
+}
+
 // ---- actor launch helpers (forward kernel + env step in one launch)
 // surplus workgroup: the leaf-range insert of this vector step (independent of the actions: new leaves get pmax)
 __device__ __forceinline__ void actor_tree_wg(const EnvArgs &e, unsigned long long c0, float *lds) {
+    // deferred rebuild of the tree top after the previous update's priority write-back: this workgroup is the next
+    // reader of those nodes (boundary siblings of the range insert), and it has slack behind the forward workgroups
+    if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
     const float pmax = e.st->pmax;
     const long long a = (long long)(c0 % (unsigned long long)e.cap);
     if (e.n <= RANGE_MAX && a + e.n <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, e.n, pmax, lds);
