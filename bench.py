@@ -57,6 +57,8 @@ def algorithmic_cost(name, L, n_params):
         return "mfma", 3 * F * B
     if name in ("act_fwd_policy", "actor_step"):      # forward + policy + env step + ring/tree insert, one launch
         return "mfma", F * N_ENVS
+    if name == "actor_steps":         # k_actor: TRAIN_FREQ vector env steps in one launch (+ leaves, + next batch's PER draw)
+        return "mfma", F * N_ENVS * TRAIN_FREQ
     if name == "td_bwd_rows":
         return "mfma", (2 * (1 + A) * H2 + 2 * H1 * H2) * B
     if name == "per_top":
@@ -69,7 +71,7 @@ def algorithmic_cost(name, L, n_params):
 PMC_KEYS = {   # bench kernel label -> (kernel name in profiles/*_pmc.json, FETCH_SIZE correction)
     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads; other widths
     # are uncalibrated and taken as reported. The forward kernel appears once per grid size (actor vs 3-pass launch).
-    "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3": ("k_qnet_fwd:max", 2.0),
+    "actor_steps": ("k_actor", 1.0), "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3": ("k_qnet_fwd:max", 2.0),
     "td_bwd_rows": ("k_bwd_rows", 2.0), "dw_adam_perwrite": ("k_dw", 2.0), "dw_perwrite": ("k_dw", 2.0), "dw_adam": ("k_dw", 2.0), "dw": ("k_dw", 2.0),
     "per_sample": ("k_per_sample", 1.0), "per_top": ("k_per_top", 1.0),
 }
@@ -303,7 +305,7 @@ def main():
             for _ in range(args.profile_steps):
                 eng.profile_begin(st)
                 if dp:
-                    eng.actor_step(st); eng.update_backward(B, st); eng.update_apply(B, st)
+                    eng.actor_backward(TRAIN_FREQ, B, st); eng.update_apply(B, st)
                 else:
                     eng.train_iters(1, TRAIN_FREQ, B, st)    # profiling mode: eager, one launch per event pair
                 for name, ms in eng.profile_end(st):
@@ -327,6 +329,7 @@ def main():
         # dominant KERNEL = largest time share per step. k_qnet_fwd is launched in two shapes (4 actor launches of
         # 256 rows + 1 three-pass launch of 3x1024 rows): its roofline entry aggregates all five launches of a step.
         groups = {"k_qnet_fwd": [k for k in ("actor_step", "qnet_fwd_x3", "sample_fwd_x3") if k in per_step]}
+        fwd_shapes = " + ".join(f"{per_step[k]['launches_per_step']} x {k}" for k in groups["k_qnet_fwd"])
         for k in per_step:
             if k not in groups["k_qnet_fwd"]:
                 groups[k] = [k]
@@ -340,7 +343,7 @@ def main():
         tr = [pmc_traffic(k) for k in ks]
         roof = {"bound": bound, "achieved": ach, "peak": peak, "unit": per_step[ks[0]]["unit"], "frac": ach / peak,
                 "traffic": (sum(t * per_step[k]["launches_per_step"] for t, k in zip(tr, ks)) / nl) if all(t is not None for t in tr) else None,
-                "kernel": dom + (" (per step: 4 actor launches of 256 rows + 1 launch of 3x1024 rows; per-shape lines under \"kernels\")" if dom == "k_qnet_fwd" else ""),
+                "kernel": dom + (f" (per step: {fwd_shapes}; per-shape lines under \"kernels\")" if dom == "k_qnet_fwd" else ""),
                 "avg_us": gtime[dom] / nl, "launches_per_step": nl,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r*_pmc.json, bytes per launch",
                 "timing": "hipExtLaunchKernelGGL start/stop events of each eager launch on the launch stream, median of "

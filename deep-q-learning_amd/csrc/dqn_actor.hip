@@ -1,0 +1,490 @@
+// csrc/dqn_actor.hip -- the vector actor of the inner loop (q_agent.py:176-183) for T consecutive env steps in
+// ONE launch, exact-f32 path.
+//
+// Between two updates the online parameters do not change and the envs do not interact, so the T = train_frequency
+// actor steps of an iteration (q_agent.py:186) are T dependent forwards of the SAME rows through the SAME weights.
+// One workgroup owns 4 envs ("tile") for the whole launch:
+//   * its slab of W1 / W2 (column 64*wave + lane, every k) is fetched ONCE into registers straight from the
+//     canonical [in,out] row-major parameters (a k-row of 64 columns = one coalesced 256-B wave load; no packing);
+//   * every layer is a chain of v_mfma_f32_4x4x1_16b_f32: 16 blocks of 4x4, K = 1, i.e. 4 rows x 64 columns per
+//     instruction -- the narrowest row tile the matrix core offers at the full f32 rate, so a 256x256 layer costs
+//     256 issues per wave instead of the 1024 of a 16-row tile. One fused multiply-add per (row, column, k) in
+//     ascending k: bit-for-bit the fmaf chain of the CPU restatement (and of the 16x16x4 kernels of dqn_net.hip);
+//   * the two skinny heads (4 rows x (1+A) columns, K = H2) run as 4*(1+A) VALU fmaf chains out of LDS;
+//   * the env state never leaves LDS between steps; ring rows go straight to their (deterministic) slots
+//     counter + t*n + i (replay_buffer.py:58-65).
+// Riding in the same launch, off the actors' critical path:
+//   * workgroup 0 rebuilds the tree top left stale by the previous update's priority write-back and inserts the
+//     T*n new leaves (all at the running max priority, one contiguous range), then releases a flag;
+//   * ceil(B/16) sampler workgroups wait for that flag and draw the NEXT update's stratified PER batch (indices, raw
+//     IS weights, batch max) -- the tree is final once the leaves are in, whatever the actors are still doing; the
+//     sampled rows themselves are gathered by the forward launch that follows (SampleArgs.pre).
+#include "dqn_device.h"
+#include "dqn_launch.h"
+#include "dqn_per_device.h"
+#include "dqn_net_common.h"
+
+#define MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+#ifdef DQN_STAMPS
+extern __device__ unsigned long long g_stamps[8][64][2];
+#define ASTAMP(S)                                                                             \
+    do { if (threadIdx.x == 0 && wg == 0) {                                                    \
+             g_stamps[7][S][0] = __builtin_amdgcn_s_memtime();                                 \
+             g_stamps[7][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define BSTAMP(S)                                                                             \
+    do { if (threadIdx.x == 0) {                                                               \
+             g_stamps[3][S][0] = __builtin_amdgcn_s_memtime();                                 \
+             g_stamps[3][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define ASTAMP(S) do { } while (0)
+#define BSTAMP(S) do { } while (0)
+#endif
+
+struct ActorArgs {
+    EnvArgs env;                 // envs, ring, tree, device state
+    int T;                       // vector env steps taken by this launch
+    const float *params;         // canonical online parameters (LunarLander/dddqn.py:19-22 leaf order)
+    const float *pack;           // their packed shadows (p_w2k: k-packed W2, p_wht: heads)
+    int32_t *act_out;            // [n] actions of the last step
+    int tiles, G;                // 4-env tiles, actor workgroups (tile = wg, wg + G, ...)
+    int n_tree, n_smp;           // role split of the grid: [tree][actors x G][samplers x n_smp]
+    int B; SampleArgs smp;       // presampling of the next update's batch (n_smp > 0)
+};
+
+// ---- one sampler workgroup: 16 batch rows, 16 lanes per row, 4 tree levels per memory round trip (the descent of
+// sample_tile_coop in dqn_per_device.h: same compares / subtractions in the same order, hence the same leaves)
+__device__ __forceinline__ void presample_tile(const SampleArgs &s, int row0, int B, int tid, long long size,
+                                               float *lsub, float *lw) {
+    const int g = tid >> 4, j = tid & 15;
+    const int k = row0 + g, kk = k < B ? k : B - 1;
+    const unsigned long long ctr = s.st->sample_ctr;
+    const float beta = s.st->beta;
+    const float total = s.tree[1];
+    const float seg = __fdiv_rn(total, (float)B);
+    const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
+    float u = ((float)kk + u01(o.x)) * seg;
+    long long cur = 1;
+    float *sub = lsub + g * 32;
+    for (int done = 0; done < s.L; done += 4) {
+        const int nl = s.L - done < 4 ? s.L - done : 4;
+        const int cnt = (2 << nl) - 2;
+        for (int f = j; f < cnt; f += 16) {
+            const int t = 31 - __clz(f + 2), i = f + 2 - (1 << t);
+            sub[f] = s.tree[(cur << t) + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // a row group lives inside one wave
+        int p = 0;
+        for (int t = 1; t <= nl; ++t) {
+            const float l = sub[(1 << t) - 2 + 2 * p];
+            if (u < l) { p = 2 * p; }
+            else { u = u - l; p = 2 * p + 1; }
+        }
+        cur = (cur << nl) + p;
+    }
+    long long leaf = cur - s.N;
+    if (leaf >= size) leaf = size - 1;
+    if (j == 0) {
+        const float w = pow_det(__fdiv_rn((float)size * s.tree[s.N + leaf], total), -beta);
+        lw[g] = k < B ? w : 0.0f;
+        if (k < B) { s.idx[k] = (int32_t)leaf; s.w_raw[k] = w; }
+    }
+    LDS_BARRIER();
+    if (tid == 0) {
+        float mx = 0.0f;
+        for (int q = 0; q < 16; ++q) mx = fmaxf(mx, lw[q]);
+        atomicMax(reinterpret_cast<unsigned int *>(&s.st->wmax), __float_as_uint(mx));
+    }
+}
+
+// KB = 16-row k-blocks of the register-resident W2 slab: hidden1 <= 16*KB (columns / rows past hidden1 are zeros, and
+// x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
+// KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
+template <int KB, int KB2>
+__global__ void __launch_bounds__(256)
+k_actor(NetDims m, ActorArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const EnvArgs &e = g.env;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
+    const unsigned long long nT = (unsigned long long)g.T * (unsigned long long)e.n, c1 = c0 + nT;
+    const unsigned total_wgs = gridDim.x;
+    int role = 1, wg = (int)blockIdx.x - g.n_tree;
+    if ((int)blockIdx.x < g.n_tree) role = 0;
+    else if (wg >= g.G) { role = 2; wg -= g.G; }
+
+    if (role == 0) {
+        // ---- tree workgroup: deferred top rebuild, then the leaves of all T steps (q_agent.py:182 x T; pmax only moves
+        // in a priority write-back, so the T inserts of the sequential loop are one range insert)
+        BSTAMP(0);
+        if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
+        BSTAMP(1);
+        const float pmax = e.st->pmax;
+        const long long a = (long long)(c0 % (unsigned long long)e.cap);
+        if (nT <= RANGE_MAX && a + (long long)nT <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, (int)nT, pmax, lds);
+        else per_add_slow(e.tree, e.Nt, e.L, c0, (int)nT, pmax, e.cap);
+        BSTAMP(2);
+        if (g.n_smp > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // each thread: its tree stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&e.st->tree_ready, c1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        BSTAMP(3);
+    } else if (role == 2) {
+        // ---- sampler workgroup: q_agent.py:147-153 for the update that follows this launch
+        if (wg == 0) BSTAMP(4);
+        if (tid == 0)
+            while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != c1)
+                __builtin_amdgcn_s_sleep(4);
+        if (wg == 0) BSTAMP(5);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (wg == 0) BSTAMP(6);
+        const long long size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);
+        const int ntile = (g.B + 15) / 16;
+        for (int tile = wg; tile < ntile; tile += g.n_smp) {
+            presample_tile(g.smp, tile * 16, g.B, tid, size, lds, lds + 512);
+            LDS_BARRIER();                                                   // lw is rewritten by the next tile
+        }
+        if (wg == 0) BSTAMP(7);
+    } else {
+        // ---- actor workgroup
+        const int D = m.D, H1 = m.H1, H2 = m.H2, A = m.A;
+        const int DP = (D + 3) & ~3;
+        const int sx = DP + 4, s1 = 16 * KB + 4, s2 = 16 * KB2 + 4;
+        float *lx = lds, *l1 = lx + 4 * sx, *l2 = l1 + 4 * s1, *lwh = l2 + 4 * s2, *lq = lwh + (A + 1) * s2;
+        int *lt = reinterpret_cast<int *>(lq + 64);                          // CartPole step counters of the tile
+        float *lrand = lq + 64 + 4;                                          // [4][4]: policy u, random action, done, reward
+        volatile int *lflag = reinterpret_cast<volatile int *>(lrand + 16);  // [3]: draws of waves 1..3 are in LDS
+        const float *P = g.params;
+        const int r4 = lane & 3;
+        ASTAMP(0);
+
+        // Requests in the order their data is needed (vector-memory returns are in order): the first tile's rows, the
+        // heads' weights (staged in LDS), the W1 slab + biases, last the big W2 slab. Unconditional requests at clamped
+        // indices + selects (a branch around a load would put a wait in front of it); SGPR-descriptor buffer loads
+        // (uniform row offset in soffset, the lane's column in voffset: no per-lane 64-bit address arithmetic).
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (int)(m.P * 4), 0x00020000);
+        auto ldP = [&](unsigned voff_elems, long long soff_elems) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsP, (int)(voff_elems * 4u), (int)(soff_elems * 4), 0));
+        };
+        const unsigned col = 64u * wave + lane;
+        const unsigned cc1 = col < (unsigned)H1 ? col : (unsigned)H1 - 1u, cc2 = col < (unsigned)H2 ? col : (unsigned)H2 - 1u;
+        float x0;                                                            // element tid of the first tile's lx image
+        {
+            const int il = tid / sx, el = tid - il * sx, i = 4 * wg + il;
+            const bool ok = tid < 4 * sx && i < e.n && el < D;
+            const float v = e.env_obs[ok ? (long long)i * D + el : 0];
+            x0 = ok ? v : 0.0f;
+        }
+        // heads, from the fragment-ordered transposed shadow (dqn_net.hip: packed(WH^T), K = 1+A padded to 16, C = H2):
+        // float4 number ct*64 + ln holds WH^T[4j + (ln>>4)][16ct + (ln&15)], j = 0..3
+        const float4 *pwht = reinterpret_cast<const float4 *>(g.pack + m.p_wht);
+        const int nq4 = 4 * H2;
+        float4 whv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int q = tid + 256 * u; whv[u] = pwht[q < nq4 ? q : nq4 - 1]; }
+        // the slabs are read through descriptors that end with the matrix: rows past obs_dim / hidden1 (the zero padding
+        // of the size class) are out of range and come back as 0.0 from the bounds check, with no select in the way
+        const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + m.o_w1), 0, D * H1 * 4, 0x00020000);
+        float w1r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            w1r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW1, (int)(cc1 * 4u), k * H1 * 4, 0));
+        float b1r = ldP(cc1, m.o_b1), b2r = ldP(cc2, m.o_b2);
+        const int hr = lane & 3, hc = lane >> 2;                             // head chain of this lane (wave 0)
+        const bool hlane = wave == 0 && hc <= A;
+        float bh = ldP((unsigned)((hc == 0 || hc > A) ? (int)m.o_bv : (int)m.o_ba + hc - 1), 0);
+        float eps = e.st->epsilon;
+        ASTAMP(20);
+        // zero images: h1 / h2 columns past hidden1 / hidden2 and the heads' padding stay zero for the whole launch
+        for (int t = tid; t < 4 * s1 + 4 * s2 + (A + 1) * s2; t += 256) l1[t] = 0.0f;
+        if (tid < 3) lflag[tid] = 0;
+        LDS_BARRIER();
+        ASTAMP(21);
+        // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tid + 256 * u, ct = q >> 6, ln = q & 63, gq = ln >> 4, k = 16 * ct + (ln & 15);
+            if (q < nq4) {
+                if (gq <= A) lwh[gq * s2 + k] = whv[u].x;
+                if (4 + gq <= A) lwh[(4 + gq) * s2 + k] = whv[u].y;
+                if (8 + gq <= A) lwh[(8 + gq) * s2 + k] = whv[u].z;
+                if (12 + gq <= A) lwh[(12 + gq) * s2 + k] = whv[u].w;
+            }
+        }
+        // first tile's rows; every compiler-tracked request above has now been waited for, so none of its waits can
+        // be held up by the untracked slab requests that follow
+        if (tid < 4 * sx) lx[tid] = x0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+        asm volatile("" : "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(eps));
+        ASTAMP(22);
+        // The W2 slab goes straight to its final registers as 16-B loads of the k-packed shadow (four consecutive k of
+        // the lane's column; measured 69 B/clk/CU against 36 for dword rows): k < 64 to architectural VGPRs, the rest to
+        // accumulation VGPRs (the ISA addresses 256 of each; the matrix core reads its B operand from either file).
+        // Inline asm, because the compiler would stage every row in an architectural VGPR first (all live at once:
+        // spills, serialised copies); such loads are invisible to its wait insertion, hence the explicit s_waitcnt below.
+        f32x4 w2q[4 * KB];
+        {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const unsigned long long base = reinterpret_cast<unsigned long long>(g.pack + m.p_w2k);
+            const i32x4 rs = {(int)(unsigned)(base & 0xffffffffull), (int)(unsigned)(base >> 32), H1 * H2 * 4, 0x00020000};
+            const int voff = (int)(cc2 * 16u);
+#pragma unroll
+            for (int kq = 0; kq < 4 * KB; ++kq) {
+                const int soff = kq * H2 * 16;                               // rows past hidden1: out of range => 0.0
+                if (kq < 16) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w2q[kq]) : "v"(voff), "s"(rs), "s"(soff));
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(w2q[kq]) : "v"(voff), "s"(rs), "s"(soff));
+            }
+        }
+        ASTAMP(23);
+        // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
+        const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
+        bool w2_landed = false;
+
+        for (int tile = wg; tile < g.tiles; tile += g.G) {
+            const int i0 = 4 * tile;
+            const int cnt = e.n - i0 < 4 ? e.n - i0 : 4;
+            LDS_BARRIER();                                                   // previous tile's LDS is dead
+            for (int t = tid + (tile == wg ? 256 : 0); t < 4 * sx; t += 256) {   // (first tile: elements 0..255 are staged)
+                const int il = t / sx, el = t - il * sx;
+                lx[t] = (il < cnt && el < D) ? e.env_obs[(long long)(i0 + il) * D + el] : 0.0f;
+            }
+            if (e.kind == 1 && tid < 4) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
+            LDS_BARRIER();
+            ASTAMP(1);
+
+            for (int t = 0; t < g.T; ++t) {
+                const bool last = t == g.T - 1;
+                const unsigned long long ect = ec + (unsigned long long)t;
+                const long long at = a0 + (long long)t * e.n + i0;              // slot of the tile's first env, before the wrap
+                const int flagv = (tile - wg) / g.G * g.T + t + 1;              // value the draw flags take in this step
+                // The slabs live in registers for the whole launch: the empty asm makes their values opaque here, so
+                // the compiler can neither re-request them from memory inside the step loop nor forget them.
+#pragma unroll
+                for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+                asm volatile("" : "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(eps));
+                // layer 1: h1 = relu(x @ w1 + b1)                              dddqn.py:25-26
+                {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *ar = lx + r4 * sx;
+                    if (D <= 16) {
+                        float4 ab[4];
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) ab[kq] = *reinterpret_cast<const float4 *>(ar + (4 * kq < DP ? 4 * kq : 0));
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) {
+                            if (4 * kq < DP) {
+                                acc = MFMA1(ab[kq].x, w1r[4 * kq + 0], acc);
+                                acc = MFMA1(ab[kq].y, w1r[4 * kq + 1], acc);
+                                acc = MFMA1(ab[kq].z, w1r[4 * kq + 2], acc);
+                                acc = MFMA1(ab[kq].w, w1r[4 * kq + 3], acc);
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < D; ++k) acc = MFMA1(ar[k], ldP(cc1, m.o_w1 + (long long)k * H1), acc);
+                    }
+                    if (col < (unsigned)H1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float v = acc[r] + b1r; l1[r * s1 + col] = v > 0.0f ? v : 0.0f; }
+                    }
+                }
+                if (!w2_landed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2_landed = true; ASTAMP(24); }
+                LDS_BARRIER();
+                ASTAMP(2 + 4 * t);
+#pragma unroll
+                for (int kq = 0; kq < 4 * KB; ++kq) {
+                    if (kq < 16) asm volatile("" : "+v"(w2q[kq]));
+                    else asm volatile("" : "+a"(w2q[kq]));
+                }
+                // layer 2: h2 = relu(h1 @ w2 + b2)                             dddqn.py:27-28
+                // A operand (4 consecutive k of this lane's row) read from LDS four groups ahead of its MFMAs
+                {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *ar = l1 + r4 * s1;
+                    float4 ab[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ab[q] = *reinterpret_cast<const float4 *>(ar + 4 * q);
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 a4 = ab[u];
+                            if (kb + 1 < KB) ab[u] = *reinterpret_cast<const float4 *>(ar + 16 * (kb + 1) + 4 * u);
+                            acc = MFMA1(a4.x, w2q[4 * kb + u][0], acc);
+                            acc = MFMA1(a4.y, w2q[4 * kb + u][1], acc);
+                            acc = MFMA1(a4.z, w2q[4 * kb + u][2], acc);
+                            acc = MFMA1(a4.w, w2q[4 * kb + u][3], acc);
+                            __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads four groups ahead
+                        }
+                    }
+                    if (col < (unsigned)H2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float v = acc[r] + b2r; l2[r * s2 + col] = v > 0.0f ? v : 0.0f; }
+                    }
+                }
+                LDS_BARRIER();
+                ASTAMP(3 + 4 * t);
+                if (wave == 0) {
+                    // heads (dddqn.py:29-30): 4 rows x (1+A) columns = 4*(1+A) fmaf chains over hidden2, one per lane
+                    if (hlane) {
+                        const float *ar = l2 + hr * s2, *wr = lwh + hc * s2;
+                        float acc = 0.0f;
+                        float4 ab[4], wb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { ab[q] = *reinterpret_cast<const float4 *>(ar + 4 * q); wb[q] = *reinterpret_cast<const float4 *>(wr + 4 * q); }
+#pragma unroll
+                        for (int kb = 0; kb < KB2; ++kb) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 a4 = ab[q], w4 = wb[q];
+                                if (kb + 1 < KB2) {
+                                    ab[q] = *reinterpret_cast<const float4 *>(ar + 16 * (kb + 1) + 4 * q);
+                                    wb[q] = *reinterpret_cast<const float4 *>(wr + 16 * (kb + 1) + 4 * q);
+                                }
+                                acc = fmaf(a4.x, w4.x, acc); acc = fmaf(a4.y, w4.y, acc);
+                                acc = fmaf(a4.z, w4.z, acc); acc = fmaf(a4.w, w4.w, acc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        lq[hr * 16 + hc] = acc + bh;
+                    }
+                    if (t == 1) ASTAMP(25);
+                    // the random draws of this step were made by waves 1..3 meanwhile
+                    while (lflag[0] != flagv || lflag[1] != flagv || lflag[2] != flagv) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order
+                    if (t == 1) ASTAMP(26);
+                    if (lane < cnt) {
+                        // dueling combine (dddqn.py:31) + epsilon-greedy (q_agent.py:137-141, compute_action :70)
+                        const int il = lane, i = i0 + il;
+                        const float *hrow = lq + il * 16;
+                        float sum = 0.0f, qrow[16];
+                        for (int a = 0; a < A; ++a) sum = sum + hrow[1 + a];
+                        const float mean = __fdiv_rn(sum, (float)A);
+                        for (int a = 0; a < A; ++a) qrow[a] = (hrow[0] + hrow[1 + a]) - mean;
+                        int act = 0;
+                        for (int a = 1; a < A; ++a) if (qrow[a] > qrow[act]) act = a;
+                        if (!(eps < lrand[il * 4 + 0])) act = __float_as_int(lrand[il * 4 + 1]);
+                        if (last) g.act_out[i] = act;
+                        // the action-dependent part of the transition (q_agent.py:177-183)
+                        long long k = at + il; if (k >= e.cap) k -= e.cap;
+                        if (e.kind == 1) {
+                            float sv[4];
+                            for (int j = 0; j < 4; ++j) { sv[j] = lx[il * sx + j]; e.states[k * 4 + j] = sv[j]; }
+                            const bool term = cartpole_step(sv, act);
+                            const int tt = lt[il] + 1;
+                            const bool done = term || tt >= e.max_steps;             // q_agent.py:179-180
+                            for (int j = 0; j < 4; ++j) e.observations[k * 4 + j] = sv[j];
+                            e.actions[k] = act; e.rewards[k] = term ? e.term_reward : 1.0f; e.dones[k] = done ? 1 : 0;
+                            if (done) {
+                                atomicAdd(&e.st->ep_count, 1ull);
+                                atomicAdd(&e.st->ep_steps, (unsigned long long)tt);
+                                const u32x4 o = philox_draw(e.seed, ect, (uint32_t)i, DQN_STREAM_ENV);
+                                sv[0] = (u01(o.x) * 0.1f) - 0.05f; sv[1] = (u01(o.y) * 0.1f) - 0.05f;
+                                sv[2] = (u01(o.z) * 0.1f) - 0.05f; sv[3] = (u01(o.w) * 0.1f) - 0.05f;
+                            }
+                            lt[il] = done ? 0 : tt;
+                            for (int j = 0; j < 4; ++j) lx[il * sx + j] = sv[j];
+                            if (last) {
+                                e.env_t[i] = done ? 0 : tt;
+                                for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = sv[j];
+                            }
+                        } else {
+                            e.actions[k] = act;                                      // replay_buffer.py:60
+                            e.rewards[k] = lrand[il * 4 + 3];                        // :61
+                            e.dones[k] = lrand[il * 4 + 2] != 0.0f ? 1 : 0;          // :63
+                        }
+                    }
+                } else {
+                    // waves 1..3, meanwhile: every Philox draw of the step (none depends on the forward pass) -- the
+                    // policy's (u, random action), and for the synthetic env the next observations (written to the ring
+                    // and to the LDS state right here) and the (reward, done) pairs
+                    const int nobs = e.kind == 0 ? cnt * D : 0;
+                    for (int u = tid - 64; u < nobs + 2 * cnt; u += 192) {
+                        if (u < nobs) {
+                            const int il = u / D, el = u - il * D, i = i0 + il;
+                            long long k = at + il; if (k >= e.cap) k -= e.cap;
+                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
+                            const float nx = ih_normal(o);
+                            e.states[k * D + el] = lx[il * sx + el];                 // replay_buffer.py:59
+                            e.observations[k * D + el] = nx;                         // :62
+                            lx[il * sx + el] = nx;                                   // q_agent.py:183 (read by this thread only)
+                            if (last) e.env_obs[(long long)i * D + el] = nx;
+                        } else if (u < nobs + cnt) {
+                            const int il = u - nobs, i = i0 + il;
+                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)i, DQN_STREAM_POLICY);   // as policy_row()
+                            lrand[il * 4 + 0] = u01(o.x);
+                            lrand[il * 4 + 1] = __int_as_float((int)(((unsigned long long)o.y * (unsigned long long)A) >> 32));
+                        } else if (e.kind == 0) {
+                            const int il = u - nobs - cnt, i = i0 + il;
+                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + D), DQN_STREAM_ENV);
+                            const bool done = u01(o.x) < e.p_done;
+                            float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
+                            if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
+                            lrand[il * 4 + 2] = done ? 1.0f : 0.0f;
+                            lrand[il * 4 + 3] = rew;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes are done ...
+                    if (lane == 0) lflag[wave - 1] = flagv;                      // ... before its flag
+                }
+                LDS_BARRIER();
+                ASTAMP(4 + 4 * t);
+                ASTAMP(5 + 4 * t);
+            }
+        }
+    }
+
+    // the last workgroup of the launch to arrive commits the counters (every thread's stores depend on c0 / ec, so a
+    // workgroup that reaches this barrier has finished reading them)
+    LDS_BARRIER();
+    if (tid == 0) {
+        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
+        if (ticket == total_wgs - 1u) {
+            e.st->ring_counter = c1;                                                              // replay_buffer.py:64
+            e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
+            e.st->env_ctr = ec + (unsigned long long)g.T;
+            e.st->arrive = 0;
+        }
+    }
+}
+
+// host side -------------------------------------------------------------------------------------------------
+bool actor_multi_supported(const NetDims &m, int n_envs, int T) {
+    (void)n_envs;
+    return T >= 1 && m.H1 <= 256 && m.H2 <= 256 && m.D <= 256;
+}
+
+void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
+                        int32_t *act_out, int B, const SampleArgs *smp) {
+    ActorArgs g{};
+    g.env = env; g.T = T; g.params = params; g.pack = pack; g.act_out = act_out;
+    // the register-resident weight slab limits a CU to ONE workgroup of this kernel, whatever its role: keep the
+    // grid within the 256 CUs so that tree, sampler and actor workgroups all run side by side
+    g.n_tree = env.tree ? 1 : 0;
+    g.n_smp = (smp && env.tree && B > 0) ? (B + 15) / 16 : 0;
+    if (g.n_smp > 64) g.n_smp = 64;
+    g.tiles = (env.n + 3) / 4;
+    const int room = 255 - g.n_tree - g.n_smp;
+    g.G = g.tiles < room ? g.tiles : room;
+    g.B = B;
+    if (g.n_smp) g.smp = *smp;
+    const int DP = (m.D + 3) & ~3;
+    const int KB = m.H1 <= 16 ? 1 : (m.H1 <= 32 ? 2 : (m.H1 <= 64 ? 4 : (m.H1 <= 128 ? 8 : 16)));
+    const int KB2 = m.H2 <= 64 ? 4 : 16;
+    size_t lds = sizeof(float) * (4 * (size_t)(DP + 4) + 4 * (size_t)(16 * KB + 4) + 4 * (size_t)(16 * KB2 + 4) +
+                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 16 + 4);
+    if (g.n_tree) {
+        const size_t nT = (size_t)T * (size_t)env.n;
+        size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : 0) + 2) + 64);
+        if (lds < need) lds = need;
+        if (env.rebuild_top) { need = sizeof(float) * ((size_t)1 << (env.L < PW_TOP ? env.L : PW_TOP)); if (lds < need) lds = need; }
+    }
+    if (g.n_smp && lds < sizeof(float) * 528) lds = sizeof(float) * 528;
+    const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
+#define ACTOR_CASE(K1, K2) if (KB == K1 && KB2 == K2) { DQN_LAUNCH((k_actor<K1, K2>), grid, block, lds, s, m, g); return; }
+    ACTOR_CASE(1, 4) ACTOR_CASE(2, 4) ACTOR_CASE(4, 4) ACTOR_CASE(8, 4) ACTOR_CASE(16, 4)
+    ACTOR_CASE(1, 16) ACTOR_CASE(2, 16) ACTOR_CASE(4, 16) ACTOR_CASE(8, 16) ACTOR_CASE(16, 16)
+#undef ACTOR_CASE
+}

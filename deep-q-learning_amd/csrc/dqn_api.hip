@@ -486,7 +486,7 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
 // fuse_adam: optimizer applied in the dW epilogue (single GPU). fork: run the PER write-back on a
 // parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
 static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fuse_pw = false,
-                             bool defer_top = false) {
+                             bool defer_top = false, bool presampled = false) {
     // q_agent.py:147-153 sample_batch + :159-165 compute_q_targets' three forwards, ONE launch: every forward
     // workgroup draws its own 16 rows (stratified PER descent or uniform Philox index) and reads them from the ring
     SampleArgs sm{};
@@ -494,6 +494,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     sm.states = h->states; sm.observations = h->observations; sm.rewards = h->rewards; sm.actions = h->actions;
     sm.dones = h->dones; sm.seed = h->cfg.seed;
     sm.idx = h->bidx; sm.a = h->ba; sm.r = h->br; sm.w_raw = h->bw_raw; sm.d = h->bd;
+    sm.pre = presampled ? 1 : 0;         // idx / w_raw / wmax drawn by the actor launch that precedes (dqn_actor.hip)
     FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, nullptr, h->q, nullptr, true),
                      make_pass(h, DQN_NET_ONLINE, nullptr, h->nq, nullptr, false),
                      make_pass(h, DQN_NET_TARGET, nullptr, h->nt, nullptr, false) };
@@ -533,28 +534,51 @@ static void enqueue_apply(dqn_handle *h, int B, hipStream_t st) {
 // the whole Agent._step. Single GPU: optimizer fused into the dW epilogue, and the PER write-back waves
 // ride in the same launch as surplus workgroups (a forked graph branch measured slower: cross-queue
 // dependencies cost more than they hide).
-static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing, bool defer_top = false) {
+static void enqueue_update(dqn_handle *h, int B, hipStream_t st, bool capturing, bool defer_top = false,
+                           bool presampled = false) {
     (void)capturing;
     if (h->world == 1) {
-        enqueue_backward(h, B, st, true, true, defer_top);
+        enqueue_backward(h, B, st, true, true, defer_top, presampled);
     } else {
-        enqueue_backward(h, B, st, false, true);
+        enqueue_backward(h, B, st, false, true, false, presampled);
         enqueue_apply(h, B, st);
     }
 }
 
-// q_agent.py:176-183 for n_envs device-resident synthetic envs: two kernels
-static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuild_top = false) {
-    // ONE launch: forward + epsilon-greedy policy (:176), then per workgroup the synthetic transition, ring insert
-    // and state = observation of its 16 envs (:177-183); a surplus workgroup inserts the new leaves into the tree.
-    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);
-    p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
+static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
     EnvArgs e{};
     e.st = h->st; e.states = h->states; e.actions = h->actions; e.rewards = h->rewards; e.observations = h->observations;
     e.dones = h->dones; e.cap = h->cfg.capacity; e.tree = h->cfg.use_per ? h->tree : nullptr; e.Nt = h->Ntree; e.L = h->L;
     e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
     e.kind = h->env_kind; e.max_steps = h->env_max_steps; e.env_t = h->env_t; e.term_reward = h->env_term_reward;
     e.rebuild_top = (rebuild_top && h->cfg.use_per) ? 1 : 0;
+    return e;
+}
+
+// q_agent.py:176-183 x T in ONE launch (exact-f32 path, dqn_actor.hip): T dependent vector env steps with the weights
+// resident in registers, the T*n new leaves inserted by a side workgroup, and -- presample_B > 0 -- the stratified PER
+// draw of the update that follows done by further side workgroups once the leaves are in.
+static bool actor_multi_ok(dqn_handle *h, int n_envs, int T) {
+    return !h->bf16 && T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
+}
+static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
+    const EnvArgs e = env_args(h, n_envs, rebuild_top);
+    SampleArgs sm{};
+    sm.st = h->st; sm.tree = h->tree; sm.N = h->Ntree; sm.L = h->L; sm.seed = h->cfg.seed;
+    sm.idx = h->bidx; sm.w_raw = h->bw_raw;
+    arm(h);
+    launch_actor_multi(st, h->m, e, T, h->params, h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm);
+    mark(h, st, "actor_steps");
+}
+
+// q_agent.py:176-183 for n_envs device-resident synthetic envs: two kernels
+static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuild_top = false) {
+    // ONE launch: forward + epsilon-greedy policy (:176), then per workgroup the synthetic transition, ring insert
+    // and state = observation of its 16 envs (:177-183); a surplus workgroup inserts the new leaves into the tree.
+    if (actor_multi_ok(h, n_envs, 1)) { enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0); return; }
+    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);
+    p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
+    const EnvArgs e = env_args(h, n_envs, rebuild_top);
     arm(h);
     L_fwd(h, st, &p, 1, n_envs, &e);
     mark(h, st, "actor_step");
@@ -669,6 +693,11 @@ extern "C" int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_en
     hipStream_t st = (hipStream_t)stream;
     const std::vector<int> key{-1, env_steps, n_envs, B};
     return run_captured(h, &h->loop_graphs[key], st, [&] {
+        if (env_steps > 0 && actor_multi_ok(h, n_envs, env_steps)) {
+            enqueue_actor_multi(h, env_steps, n_envs, st, false, B);
+            enqueue_backward(h, B, st, false, true, false, h->cfg.use_per != 0);
+            return;
+        }
         for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st);
         enqueue_backward(h, B, st, false, true);
     });
@@ -691,6 +720,15 @@ extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps
         // that the tree is consistent when the graph ends.
         // (measured: +4.8 % on the f32 path whose actor forward is long enough to hide it, -1 % on bf16: f32 only)
         const bool can_defer = env_steps > 0 && h->cfg.use_per && !h->bf16;
+        if (env_steps > 0 && actor_multi_ok(h, n_envs, env_steps)) {
+            // f32: the env_steps actor steps of an iteration are ONE launch, which also inserts their leaves and draws
+            // the update's PER batch on side workgroups
+            for (int it = 0; it < n_iters; ++it) {
+                enqueue_actor_multi(h, env_steps, n_envs, st, can_defer && it > 0, B);
+                enqueue_update(h, B, st, st && !h->profiling, can_defer && it + 1 < n_iters, h->cfg.use_per != 0);
+            }
+            return;
+        }
         for (int it = 0; it < n_iters; ++it) {
             for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st, can_defer && it > 0 && e == 0);
             enqueue_update(h, B, st, st && !h->profiling, can_defer && it + 1 < n_iters);

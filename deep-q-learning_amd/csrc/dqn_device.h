@@ -31,6 +31,8 @@ struct DqnState {
     unsigned int       pad;
     unsigned long long ep_count;       // finished episodes of the device-resident envs (CartPole)
     unsigned long long ep_steps;       // env steps (= return, reward 1 per step) summed over finished episodes
+    unsigned long long tree_ready;     // ring counter up to which the leaves are in the tree: released by the tree
+                                       // workgroup of an actor launch, awaited by its sampler workgroups (dqn_actor.hip)
 };
 
 enum { DQN_STREAM_PER = 0, DQN_STREAM_UNIFORM = 1, DQN_STREAM_POLICY = 2, DQN_STREAM_ENV = 3 };

@@ -32,6 +32,9 @@ struct NetDims {
     long long o_w1, o_b1, o_w2, o_b2, o_wv, o_bv, o_wa, o_ba, P;
     // fragment-packed shadows of the weights, as offsets (floats) into one pack buffer:
     long long p_w1, p_w2, p_wh, p_w2t, p_wht, pack_floats;
+    // k-packed W2 for the actor kernel (dqn_actor.hip): w2k[(kq*H2 + c)*4 + j] = W2[4*kq + j][c], so that a lane's
+    // 16-B load is four consecutive k of its own column; lives behind the five fragment-ordered shadows
+    long long p_w2k;
 };
 NetDims make_dims(int D, int H1, int H2, int A);
 
@@ -76,6 +79,10 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
                      const SampleArgs *smp = nullptr);
+// T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip
+bool actor_multi_supported(const NetDims &m, int n_envs, int T);
+void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
+                        int32_t *act_out, int B, const SampleArgs *smp);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
                const float *r, const float *d, const float *isw, float gamma, int B, int A,
                float *targets, float *td, float *dq, float *loss, float *scratch);

@@ -68,6 +68,7 @@ NetDims make_dims(int D, int H1, int H2, int A) {
     m.p_wh = q;  q += (long long)H2 * 16;               // K = H2, C = 1+A (padded to 16)
     m.p_w2t = q; q += (long long)H2 * H1;               // K = H2, C = H1   (W2 transposed)
     m.p_wht = q; q += (long long)16 * H2;               // K = 1+A (padded), C = H2 (heads transposed)
+    m.p_w2k = q; q += (long long)H1 * H2;               // k-packed W2 (4 consecutive k per column)
     m.pack_floats = q;
     return m;
 }
@@ -84,7 +85,13 @@ k_pack(NetDims m, const float *__restrict__ P, float *__restrict__ pack) {
     else if (t < m.p_wh)  { base = m.p_w2;  KQ = m.H1 / 16; which = 1; }
     else if (t < m.p_w2t) { base = m.p_wh;  KQ = m.H2 / 16; which = 2; }
     else if (t < m.p_wht) { base = m.p_w2t; KQ = m.H2 / 16; which = 3; }
-    else                  { base = m.p_wht; KQ = 1;         which = 4; }
+    else if (t < m.p_w2k) { base = m.p_wht; KQ = 1;         which = 4; }
+    else {                                              // k-packed W2: u = (kq*H2 + c)*4 + j
+        const long long u = t - m.p_w2k;
+        const int j = (int)(u & 3), c = (int)((u >> 2) % m.H2), kq = (int)((u >> 2) / m.H2);
+        pack[t] = P[m.o_w2 + (long long)(4 * kq + j) * m.H2 + c];
+        return;
+    }
     const long long u = t - base;
     const int j = (int)(u & 3), lane = (int)((u >> 2) & 63);
     const long long blk = u >> 8;
@@ -246,6 +253,11 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
     }
+    // batch drawn by the preceding actor launch (dqn_actor.hip): the index is the head of the dependent chain
+    // idx -> ring row, so it is requested before anything else
+    const bool presampled = sampling && smp.pre;
+    int pre_leaf = 0;
+    if (presampled && tid < 16) pre_leaf = smp.idx[row0 + tid < B ? row0 + tid : B - 1];
     MmaLayer<TN1, 2, true> L1; MmaLayer<TN2, 16, false> L2; MmaLayer<1, 16, false> LH;
     L1.start(ps.pack + m.p_w1, m.KQ1, m.H1 / 16, wave, lane);
     float bias1[TN1], bias2[TN2], biash = 0.0f;
@@ -258,10 +270,21 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         if (c == 0) biash = ps.params[m.o_bv];
         else if (c <= m.A) biash = ps.params[m.o_ba + c - 1];
     }
+    if (presampled) {
+        // rows of this tile: requested ahead of the layer-2 weights (in-order returns); pass 0 publishes a, r, d
+        if (tid < 16) {
+            lidx[tid] = pre_leaf;
+            const int k = row0 + tid;
+            if (blockIdx.y == 0 && k < B) { smp.a[k] = smp.actions[pre_leaf]; smp.r[k] = smp.rewards[pre_leaf]; smp.d[k] = smp.dones[pre_leaf]; }
+        }
+        LDS_BARRIER();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
+    }
     L2.init(ps.pack + m.p_w2, m.H1 / 16, m.H2 / 16, wave, lane);
     L2.template load_range<0, 6>();                          // the first AHEAD k-blocks; the rest interleave with the MFMAs
     if (wave == 0) LH.init(ps.pack + m.p_wh, m.H2 / 16, 1, 0, lane);
-    if (sampling) {
+    if (sampling && !presampled) {
         // the weight requests above are in flight; now the dependent tree descent, then the gathered rows
         if (smp.tree) {
             float *lsub = reinterpret_cast<float *>(lidx + 16);
@@ -644,6 +667,7 @@ __device__ __forceinline__ void scatter_packs(const NetDims &m, int i, float v, 
         const int k = u / m.H2, n = u - k * m.H2;
         pack[m.p_w2 + pidx(m.H1 / 16, k, n)] = v;
         pack[m.p_w2t + pidx(m.H2 / 16, n, k)] = v;
+        pack[m.p_w2k + ((long long)(k >> 2) * m.H2 + n) * 4 + (k & 3)] = v;
     } else if (i >= o_wv && i < o_bv) {                 // wv[k]
         const int k = i - o_wv;
         pack[m.p_wh + pidx(m.H2 / 16, k, 0)] = v;

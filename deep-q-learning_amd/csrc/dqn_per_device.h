@@ -315,6 +315,48 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int TOP = L < PW_TOP ? L : PW_TOP;
     if (TOP == 0) return;
+    if (TOP == 14 && nt == 256) {
+        // 256 threads, full-size top: each thread owns 64 consecutive depth-14 nodes (16 requests of 16 B, all in
+        // flight at once) and reduces its private 6-level subtree in registers -- depths 13..8 never touch LDS and need
+        // no barrier; depth 8 (one node per thread) and above continue in the LDS image. Same pair sums as below.
+        const float4 *src = reinterpret_cast<const float4 *>(tree + (1 << 14) + 64 * tid);
+        float4 c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = src[u];
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { v[2 * u] = c[u].x + c[u].y; v[2 * u + 1] = c[u].z + c[u].w; }
+#pragma unroll
+        for (int d = 13, cnt = 32; d >= 8; --d, cnt >>= 1) {
+            float *dst = tree + (1 << d) + cnt * tid;                    // this thread's cnt nodes of depth d
+            if (cnt >= 4) {
+#pragma unroll
+                for (int u = 0; u < 32; u += 4) if (u < cnt) *reinterpret_cast<float4 *>(dst + u) = float4{v[u], v[u + 1], v[u + 2], v[u + 3]};
+            } else if (cnt == 2) {
+                *reinterpret_cast<float2 *>(dst) = float2{v[0], v[1]};
+            } else {
+                dst[0] = v[0];
+            }
+            if (d > 8) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (2 * u + 1 < cnt) v[u] = v[2 * u] + v[2 * u + 1];
+            }
+        }
+        top[256 + tid] = v[0];
+        __syncthreads();
+        for (int d = 7; d >= 0; --d) {
+            const int cnt = 1 << d;
+            if (tid < cnt) {
+                const int p = cnt + tid;
+                const float s = top[2 * p] + top[2 * p + 1];
+                top[p] = s;
+                tree[p] = s;
+            }
+            LDS_BARRIER();
+        }
+        __syncthreads();                                         // drain this workgroup's tree stores before it re-reads them
+        return;
+    }
     const int h = 1 << (TOP - 1);
     for (int j = tid; j < h; j += nt) {
         const float2 c = *reinterpret_cast<const float2 *>(tree + 2 * (h + j));
@@ -374,6 +416,7 @@ struct SampleArgs {
     const float *states, *observations, *rewards; const int32_t *actions; const uint8_t *dones;
     unsigned long long seed;
     int32_t *idx, *a; float *r, *w_raw; uint8_t *d;
+    int pre;                             // idx / w_raw / wmax were already drawn by the actor launch (dqn_actor.hip): gather only
 };
 
 __device__ __forceinline__ long long sample_leaf(const SampleArgs &s, int k, int B, float *w_out) {

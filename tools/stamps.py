@@ -20,7 +20,10 @@ NAMES = {0: ("k_qnet_fwd", ["start", "x staged", "L1 done", "L2 mfma done", "L2 
          4: ("k_per_write_sorted", ["start", "ownership found", "leaf + sib loads", "levels done", "end"]),
          5: ("k_bwd_rows", ["start", "prefetch issued + wmax", "td rows done", "dz2 done", "end"]),
          6: ("k_dw", ["start", "mfma loop done", "epilogue (adam) done", "end"]),
-         3: ("k_per_sample", ["start", "descent done", "gather done"])}
+         7: ("k_actor (T=4)", ["start", "weights requested, x staged"] +
+             [f"t{t} {w}" for t in range(4) for w in ("L1 done", "L2 done", "heads+policy done", "env done")]),
+         3: ("k_actor side chain (tree workgroup, then sampler workgroup 0)",
+             ["tree wg start", "top rebuilt", "leaves inserted", "flag released", "sampler start", "flag seen", "acquired", "batch drawn"])}
 
 
 def main():
@@ -39,6 +42,13 @@ def main():
     rc = eng.lib.dqn_debug_stamps(buf)
     assert rc == 0, rc
     st = np.frombuffer(buf, dtype=np.uint64).reshape(8, 64, 2).astype(np.int64)
+    pro = st[7, 20:25]
+    if pro[0, 0]:
+        print("k_actor prologue (cycles since start): " + ", ".join(
+            f"{lab} +{int(c - st[7, 0, 0])}" for lab, c in zip(("small loads issued", "zero-fill barrier", "lwh + x staged", "W2 issued", "W2 landed"), pro[:, 0])))
+    if st[7, 25, 0]:
+        print(f"k_actor step 1 heads phase (cycles since its L2 done): chain done +{int(st[7, 25, 0] - st[7, 7, 0])}, "
+              f"draw flags seen +{int(st[7, 26, 0] - st[7, 7, 0])}, policy + stores done +{int(st[7, 8, 0] - st[7, 7, 0])}")
     for k, (name, labels) in NAMES.items():
         t = st[k, :len(labels)]
         cyc = t[:, 0] - t[0, 0]; real = (t[:, 1] - t[0, 1]) * 10.0     # ns
