@@ -683,6 +683,19 @@ extern "C" int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream) {
     return run_captured(h, &h->graphs[-n_envs].actor, st, [&] { enqueue_actor(h, n_envs, st); });
 }
 
+extern "C" int dqn_actor_steps(dqn_handle *h, int32_t env_steps, int32_t n_envs, void *stream) {
+    REQUIRE(h, "null argument");
+    REQUIRE(env_steps >= 1 && env_steps <= 64, "env_steps out of range [1,64]");
+    REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch && (long long)env_steps * n_envs <= h->cfg.capacity,
+            "n_envs=%d exceeds max_batch=%d, or env_steps * n_envs exceeds the capacity", n_envs, h->cfg.max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const std::vector<int> key{-2, env_steps, n_envs, 0};
+    return run_captured(h, &h->loop_graphs[key], st, [&] {
+        if (actor_multi_ok(h, n_envs, env_steps)) enqueue_actor_multi(h, env_steps, n_envs, st, false, 0);
+        else for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st);
+    });
+}
+
 /* env_steps vector env steps + the backward half of one update as ONE graph launch (data-parallel step:
  * this, then the gradient all-reduce, then dqn_update_apply) */
 extern "C" int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_envs, int32_t B, void *stream) {

@@ -326,6 +326,10 @@ class Engine:
         """one vector env step (q_agent.py:176-183) on the device-resident synthetic envs"""
         L.check(self.lib.dqn_actor_step(self.h, self.n_envs, self._s(stream)))
 
+    def actor_steps(self, env_steps, stream=None):
+        """env_steps consecutive vector env steps in one launch (the train_frequency actor steps between two updates)"""
+        L.check(self.lib.dqn_actor_steps(self.h, int(env_steps), self.n_envs, self._s(stream)))
+
     def train_iters(self, n_iters, env_steps, B, stream=None):
         """n_iters x (env_steps vector env steps + one update) in one graph launch (q_agent.py:174-187)"""
         L.check(self.lib.dqn_train_iters(self.h, n_iters, env_steps, getattr(self, "n_envs", 0), B, self._s(stream)))

@@ -174,6 +174,10 @@ int dqn_env_config(dqn_handle *h, int32_t kind, int32_t max_steps, float term_re
 int dqn_env_stats_host(dqn_handle *h, int64_t *episodes, int64_t *episode_steps);
 int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream);
 int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
+/* env_steps consecutive vector env steps (q_agent.py:176-183 x train_frequency, between two updates the parameters do
+ * not change) as ONE launch: same transitions, ring slots and tree as env_steps calls of dqn_actor_step.
+ * env_steps * n_envs <= capacity. */
+int dqn_actor_steps(dqn_handle *h, int32_t env_steps, int32_t n_envs, void *stream);
 /* the reference's inner loop (q_agent.py:174-187) for n_iters iterations as ONE hipGraph launch:
  * each iteration = env_steps vector env steps (train_frequency) followed by one Agent._step.
  * Single-GPU path (world_size == 1). */

@@ -20,7 +20,8 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def test_cartpole_env_bitexact(dq):
+@pytest.mark.parametrize("steps_per_launch", [1, 4])
+def test_cartpole_env_bitexact(dq, steps_per_launch):
     import torch
     n, T, N, seed, max_steps = 64, 300, 1 << 15, 5, 40
     e = dq.Engine(dq.EngineConfig(obs_dim=4, hidden1=64, hidden2=64, num_actions=2, capacity=N, use_per=True,
@@ -30,8 +31,11 @@ def test_cartpole_env_bitexact(dq):
     obs = (np.random.default_rng(1).random((n, 4)).astype(np.float32) * np.float32(0.1) - np.float32(0.05)).astype(np.float32)
     e.env_reset(obs); e.set_epsilon(1.0)                       # epsilon = 1: every action is the Philox randint
     with torch.cuda.stream(e.stream):
-        for _ in range(T):
-            e.actor_step()
+        for _ in range(T // steps_per_launch):
+            if steps_per_launch == 1:
+                e.actor_step()
+            else:
+                e.actor_steps(steps_per_launch)                # k_actor: env state stays in LDS between the steps
         e.stream.synchronize()
     # CPU restatement of the same T vector steps
     rb = onp.ReplayRing(N, 4); tree = onp.SumTree(15)

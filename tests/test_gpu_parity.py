@@ -350,6 +350,47 @@ def test_actor_step_bitexact(dq, per):
     e.close()
 
 
+@pytest.mark.parametrize("dims,n,T,L_,per", [
+    ((9, 32, 64, 4), 37, 3, 8, True),        # ragged last tile (37 = 9*4 + 1), small net classes, wraps a 256-slot ring
+    ((9, 32, 64, 4), 37, 3, 8, False),       # uniform replay: no tree workgroup
+    ((8, 256, 256, 4), 256, 4, 11, True),    # the bench shape
+    ((20, 48, 80, 3), 10, 5, 7, True),       # obs_dim > 16: layer-1 weights streamed per step; odd hidden sizes
+    ((70, 16, 16, 2), 5, 2, 6, True),        # obs_dim > 60: tile rows span more than 256 LDS elements
+    ((4, 64, 64, 2), 1030, 4, 13, True),     # more tiles than actor workgroups (tile loop), T*n beyond the LDS range insert
+])
+def test_actor_steps_one_launch_bitexact(dq, dims, n, T, L_, per):
+    """dqn_actor_steps: T vector env steps in ONE launch (k_actor) must leave exactly what T sequential oracle actor
+    steps leave -- ring, tree, env observations, counters -- including ring wrap and ragged tiles."""
+    import torch
+    D = dims[0]
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=max(n, 16), seed=57)
+    cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
+    P0 = rand_params(dims, 58)
+    e.set_params(P0)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, max(n, 16), cr, ct, P0, 57)
+    obs = np.random.default_rng(59).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.1); e.set_epsilon(0.25)
+    ctr = 0
+    launches = max(2, (N + T * n - 1) // (T * n) + 1)                   # enough to wrap the ring
+    with torch.cuda.stream(e.stream):
+        for _ in range(launches):
+            for _ in range(T):
+                ctr = lrn.actor_step(obs, 0.25, 0.1, ctr)
+            e.actor_steps(T)
+        e.stream.synchronize()
+    L = dq._lib
+    assert e.replay_size() == (cr.size, cr.rb.counter)
+    got = (e.buffer(L.BUF_STATES).view(N, D), e.buffer(L.BUF_ACTIONS, torch.int32), e.buffer(L.BUF_REWARDS),
+           e.buffer(L.BUF_OBSERVATIONS).view(N, D), e.buffer(L.BUF_DONES, torch.uint8))
+    for x, y in zip(got, cr.arrays()):
+        assert np.array_equal(host(x), y)
+    assert np.array_equal(host(e.buffer(L.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
+    if per:
+        assert np.array_equal(host(e.buffer(L.BUF_TREE)), ct.tree)
+    e.close()
+
+
 def test_profile_hooks_and_error_paths(dq):
     """dqn_profile_* returns one entry per launch; bad arguments come back as errors, not crashes"""
     import torch
