@@ -70,6 +70,7 @@ struct dqn_handle {
     DqnState *st = nullptr;
     float *params = nullptr, *target = nullptr, *mu = nullptr, *nu = nullptr, *grad = nullptr;
     float *pack = nullptr, *pack_t = nullptr;
+    float *pack_act = nullptr;                                    // bf16 mode: f32 shadows for the actor kernel
     float *states = nullptr, *observations = nullptr, *rewards = nullptr;
     int32_t *actions = nullptr; uint8_t *dones = nullptr;
     float *tree = nullptr; unsigned long long *stamp = nullptr;
@@ -98,7 +99,10 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // precision dispatch
 static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pack) {
-    if (h->bf16) launch_pack_bf16(s, h->m, params, pack); else launch_pack(s, h->m, params, pack);
+    if (h->bf16) {
+        launch_pack_bf16(s, h->m, params, pack);
+        if (pack == h->pack) launch_pack(s, h->m, params, h->pack_act);   // the actor kernel reads f32 shadows of the online net
+    } else launch_pack(s, h->m, params, pack);
 }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr,
                   const SampleArgs *smp = nullptr) {
@@ -168,6 +172,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     const size_t pack_bytes = h->bf16 ? (size_t)bf16_pack_elems(h->m) * 2 : (size_t)h->m.pack_floats * 4;
     h->pack_bytes = pack_bytes;
     add(&h->pack, pack_bytes); add(&h->pack_t, pack_bytes);
+    if (h->bf16) add(&h->pack_act, (size_t)h->m.pack_floats * 4);
     add(&h->states, N * D * 4, DQN_BUF_STATES); add(&h->observations, N * D * 4, DQN_BUF_OBSERVATIONS);
     add(&h->rewards, N * 4, DQN_BUF_REWARDS); add(&h->actions, N * 4, DQN_BUF_ACTIONS);
     add(&h->dones, N, DQN_BUF_DONES);
@@ -450,9 +455,10 @@ extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, co
 }
 
 static void enqueue_adam(dqn_handle *h, hipStream_t st) {
-    (h->bf16 ? launch_adam_bf16 : launch_adam)(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack,
-                h->cfg.optimizer == DQN_OPT_ADAMW, h->cfg.b1, h->cfg.b2, h->cfg.eps, h->cfg.weight_decay,
-                1.0f / (float)h->world);
+    if (h->bf16) launch_adam_bf16(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack, h->cfg.optimizer == DQN_OPT_ADAMW,
+                                  h->cfg.b1, h->cfg.b2, h->cfg.eps, h->cfg.weight_decay, 1.0f / (float)h->world, h->pack_act);
+    else launch_adam(st, h->m, h->st, h->params, h->grad, h->mu, h->nu, h->pack, h->cfg.optimizer == DQN_OPT_ADAMW,
+                     h->cfg.b1, h->cfg.b2, h->cfg.eps, h->cfg.weight_decay, 1.0f / (float)h->world);
 }
 
 extern "C" int dqn_optimizer_step(dqn_handle *h, void *stream) {
@@ -471,7 +477,7 @@ extern "C" int dqn_train_step(dqn_handle *h, const float *s, const float *target
 // ------------------------------------------------------------------------ fused update
 static AdamArgs adam_args(dqn_handle *h) {
     return AdamArgs{h->params, h->mu, h->nu, h->pack, h->cfg.optimizer == DQN_OPT_ADAMW, h->cfg.b1, h->cfg.b2,
-                    h->cfg.eps, h->cfg.weight_decay, 1.0f / (float)h->world};
+                    h->cfg.eps, h->cfg.weight_decay, 1.0f / (float)h->world, h->pack_act};
 }
 
 static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
@@ -559,7 +565,7 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
 // resident in registers, the T*n new leaves inserted by a side workgroup, and -- presample_B > 0 -- the stratified PER
 // draw of the update that follows done by further side workgroups once the leaves are in.
 static bool actor_multi_ok(dqn_handle *h, int n_envs, int T) {
-    return !h->bf16 && T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
+    return T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
 }
 static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
     const EnvArgs e = env_args(h, n_envs, rebuild_top);
@@ -567,7 +573,9 @@ static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
     sm.st = h->st; sm.tree = h->tree; sm.N = h->Ntree; sm.L = h->L; sm.seed = h->cfg.seed;
     sm.idx = h->bidx; sm.w_raw = h->bw_raw;
     arm(h);
-    launch_actor_multi(st, h->m, e, T, h->params, h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm);
+    // bf16 mode: the actor forward stays exact f32 on the master weights (latency-bound at 4 rows per workgroup: the
+    // f32 matrix-core chain costs the same time), reading its two f32 shadows from pack_act
+    launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm);
     mark(h, st, "actor_steps");
 }
 
@@ -732,7 +740,7 @@ extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps
         // next iteration (its surplus workgroup is the next reader and has slack); the last update keeps k_per_top so
         // that the tree is consistent when the graph ends.
         // (measured: +4.8 % on the f32 path whose actor forward is long enough to hide it, -1 % on bf16: f32 only)
-        const bool can_defer = env_steps > 0 && h->cfg.use_per && !h->bf16;
+        bool can_defer = env_steps > 0 && h->cfg.use_per;
         if (env_steps > 0 && actor_multi_ok(h, n_envs, env_steps)) {
             // f32: the env_steps actor steps of an iteration are ONE launch, which also inserts their leaves and draws
             // the update's PER batch on side workgroups
@@ -742,6 +750,7 @@ extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps
             }
             return;
         }
+        can_defer = can_defer && !h->bf16;                            // (per-step bf16 actor launches: measured -1 %)
         for (int it = 0; it < n_iters; ++it) {
             for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st, can_defer && it > 0 && e == 0);
             enqueue_update(h, B, st, st && !h->profiling, can_defer && it + 1 < n_iters);

@@ -74,6 +74,7 @@ struct PwArgs {             // sorted PER write-back run by surplus workgroups o
 };
 struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU fused path) when P != NULL
     float *P, *mu, *nu, *pack; int adamw; float b1, b2, eps, wd, grad_scale;
+    float *pack_act;        // bf16 mode: f32 shadows read by the actor kernel (k-packed W2, heads), else NULL
 };
 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
@@ -137,4 +138,5 @@ void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const floa
                     const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam,
                     const PwArgs &pw);
 void launch_adam_bf16(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
-                      float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
+                      float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale,
+                      float *pack_act);

@@ -46,11 +46,6 @@ extern "C" int dqn_debug_stamps(unsigned long long *out_host) {
 // g = lane>>4 reads 4 consecutive floats = k-steps j = 0..3 of k = 4*j + g
 __device__ __forceinline__ int perm16(int c) { return ((c & 3) << 2) | (c >> 2); }
 
-// index into a packed matrix of element [k][c]; KQ = number of 16-row k-blocks
-__device__ __host__ __forceinline__ long long pidx(int KQ, int k, int c) {
-    const int kq = k >> 4, kk = k & 15;
-    return ((long long)((c >> 4) * KQ + kq)) * 256 + ((((kk & 3) << 4) | (c & 15)) << 2) + (kk >> 2);
-}
 
 NetDims make_dims(int D, int H1, int H2, int A) {
     NetDims m{};

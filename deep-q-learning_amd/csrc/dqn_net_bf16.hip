@@ -180,6 +180,10 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
 #pragma unroll
         for (int u = 0; u < 2; ++u) xv[u] = xload(tid + 256 * u);
     }
+    // batch drawn by the preceding actor launch (dqn_actor.hip): idx -> ring row is the dependent chain, requested first
+    const bool presampled = sampling && smp.pre;
+    int pre_leaf = 0;
+    if (presampled && tid < 16) pre_leaf = smp.idx[row0 + tid < B ? row0 + tid : B - 1];
     MmaLayer16<TN1, 8> L1; MmaLayer16<TN2, 8> L2; MmaLayer16<1, 8> LH;
     L1.start(pack + d.p_w1, d.KQ1, m.H1 / 16, wave, lane);
     float bias1[TN1], bias2[TN2], biash = 0.0f;
@@ -192,9 +196,19 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
         if (c == 0) biash = ps.params[m.o_bv];
         else if (c <= m.A) biash = ps.params[m.o_ba + c - 1];
     }
+    if (presampled) {
+        if (tid < 16) {
+            lidx[tid] = pre_leaf;
+            const int k = row0 + tid;
+            if (blockIdx.y == 0 && k < B) { smp.a[k] = smp.actions[pre_leaf]; smp.r[k] = smp.rewards[pre_leaf]; smp.d[k] = smp.dones[pre_leaf]; }
+        }
+        LDS_BARRIER();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) xv[u] = xload(tid + 256 * u);
+    }
     L2.start(pack + d.p_w2, d.KQ2, m.H2 / 16, wave, lane);
     if (wave == 0) LH.start(pack + d.p_wh, d.KQH, 1, 0, lane);
-    if (sampling) {
+    if (sampling && !presampled) {
         if (smp.tree) {
             float *lsub = reinterpret_cast<float *>(lidx + 16);
             sample_tile_coop(smp, row0, B, tid, blockIdx.y == 0, lidx, lsub, lsub + 512);     // ends with a barrier
@@ -566,6 +580,7 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
                 pnew = pnew + (co.neglr * u);
                 ad.P[i] = pnew;
                 scatter_packs16(m, d, i, pnew, reinterpret_cast<__bf16 *>(ad.pack));
+                if (ad.pack_act) scatter_actor_packs(m, i, pnew, ad.pack_act);
             }
         }
     }
@@ -604,13 +619,14 @@ void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const floa
 // ---------------------------------------------------------------------------- optimizer
 __global__ void __launch_bounds__(256)
 k_adam16(NetDims m, Dims16 d, DqnState *st, float *P, const float *__restrict__ g, float *mu, float *nu, __bf16 *pack,
-         int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
+         int adamw, float b1, float b2, float eps, float wd, float grad_scale, float *pack_act) {
     double b1pow, b2pow;
     const AdamCoef co = adam_coef(st, b1, b2, &b1pow, &b2pow);
     const int nP = (int)m.P;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nP; i += gridDim.x * blockDim.x) {
         const float p = adam_elem(co, g[i], P, mu, nu, i, adamw, b1, b2, eps, wd, grad_scale);
         scatter_packs16(m, d, i, p, pack);
+        if (pack_act) scatter_actor_packs(m, i, p, pack_act);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -620,9 +636,10 @@ k_adam16(NetDims m, Dims16 d, DqnState *st, float *P, const float *__restrict__ 
 }
 
 void launch_adam_bf16(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
-                      float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
+                      float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale,
+                      float *pack_act) {
     int blocks = (int)((m.P + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     DQN_LAUNCH(k_adam16, dim3(blocks), dim3(256), 0, s, m, make_dims16(m), st, params, grad, mu, nu,
-                       reinterpret_cast<__bf16 *>(pack), adamw, b1, b2, eps, wd, grad_scale);
+                       reinterpret_cast<__bf16 *>(pack), adamw, b1, b2, eps, wd, grad_scale, pack_act);
 }

@@ -62,3 +62,24 @@ __device__ __forceinline__ float adam_elem(const AdamCoef &c, float g, float *P,
     return p;
 }
 
+// index into a fragment-packed f32 matrix (dqn_net.hip) of element [k][c]; KQ = number of 16-row k-blocks
+__device__ __host__ __forceinline__ long long pidx(int KQ, int k, int c) {
+    const int kq = k >> 4, kk = k & 15;
+    return ((long long)((c >> 4) * KQ + kq)) * 256 + ((((kk & 3) << 4) | (c & 15)) << 2) + (kk >> 2);
+}
+
+// the two f32 shadows the actor kernel (dqn_actor.hip) reads -- k-packed W2 and the transposed heads -- for parameter
+// element i; in bf16 mode they live in their own f32 buffer beside the bf16 packs
+__device__ __forceinline__ void scatter_actor_packs(const NetDims &m, int i, float v, float *packf) {
+    const int o_w2 = (int)m.o_w2, o_b2 = (int)m.o_b2, o_wv = (int)m.o_wv, o_bv = (int)m.o_bv, o_wa = (int)m.o_wa, o_ba = (int)m.o_ba;
+    if (i >= o_w2 && i < o_b2) {
+        const int u = i - o_w2, k = u / m.H2, n = u - k * m.H2;
+        packf[m.p_w2k + ((long long)(k >> 2) * m.H2 + n) * 4 + (k & 3)] = v;
+    } else if (i >= o_wv && i < o_bv) {
+        packf[m.p_wht + pidx(1, 0, i - o_wv)] = v;
+    } else if (i >= o_wa && i < o_ba) {
+        const int u = i - o_wa, k = u / m.A, a = u - k * m.A;
+        packf[m.p_wht + pidx(1, 1 + a, k)] = v;
+    }
+}
+
