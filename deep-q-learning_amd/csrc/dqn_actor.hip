@@ -32,6 +32,10 @@ extern __device__ unsigned long long g_stamps[8][64][2];
     do { if (threadIdx.x == 0 && wg == 0) {                                                    \
              g_stamps[7][S][0] = __builtin_amdgcn_s_memtime();                                 \
              g_stamps[7][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define WSTAMP(S)                                                                             \
+    do { if (threadIdx.x == 64 && wg == 0) {                                                   \
+             g_stamps[7][S][0] = __builtin_amdgcn_s_memtime();                                 \
+             g_stamps[7][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define BSTAMP(S)                                                                             \
     do { if (threadIdx.x == 0) {                                                               \
              g_stamps[3][S][0] = __builtin_amdgcn_s_memtime();                                 \
@@ -39,6 +43,7 @@ extern __device__ unsigned long long g_stamps[8][64][2];
 #else
 #define ASTAMP(S) do { } while (0)
 #define BSTAMP(S) do { } while (0)
+#define WSTAMP(S) do { } while (0)
 #endif
 
 struct ActorArgs {
@@ -155,46 +160,65 @@ k_actor(NetDims m, ActorArgs g) {
         float *lx = lds, *l1 = lx + 4 * sx, *l2 = l1 + 4 * s1, *lwh = l2 + 4 * s2, *lq = lwh + (A + 1) * s2;
         int *lt = reinterpret_cast<int *>(lq + 64);                          // CartPole step counters of the tile
         float *lrand = lq + 64 + 4;                                          // [4][4]: policy u, random action, done, reward
-        volatile int *lflag = reinterpret_cast<volatile int *>(lrand + 16);  // [3]: draws of waves 1..3 are in LDS
+        int *lflag = reinterpret_cast<int *>(lrand + 16);                    // [3] (+1 pad, 16-B aligned): draws of waves 1..3 are in LDS
         const float *P = g.params;
         const int r4 = lane & 3;
         ASTAMP(0);
 
-        // Requests in the order their data is needed (vector-memory returns are in order): the first tile's rows, the
-        // heads' weights (staged in LDS), the W1 slab + biases, last the big W2 slab. Unconditional requests at clamped
-        // indices + selects (a branch around a load would put a wait in front of it); SGPR-descriptor buffer loads
-        // (uniform row offset in soffset, the lane's column in voffset: no per-lane 64-bit address arithmetic).
-        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, (int)(m.P * 4), 0x00020000);
-        auto ldP = [&](unsigned voff_elems, long long soff_elems) -> float {
-            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsP, (int)(voff_elems * 4u), (int)(soff_elems * 4), 0));
+        // Every parameter request of the prologue is an inline-asm buffer load (SGPR descriptor + 32-bit lane offset;
+        // rows past the end of a matrix are out of range and come back as 0.0 from the bounds check). The compiler does
+        // not count them, so the waits are written by hand. Order of issue = order of arrival: the first half of the W2
+        // slab leads (the compiler guards the first reuse of a few registers with a full wait: harmless while nothing is
+        // in flight), the small operands (first tile's rows, W1 slab, biases, heads) follow, and the second half of the
+        // slab goes out as soon as those have been staged; it lands behind layer 1 of the first step.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto mkrs = [](const void *ptr, int bytes) -> i32x4 {
+            const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
+            return i32x4{(int)(unsigned)(b & 0xffffffffull), (int)(unsigned)(b >> 32), bytes, 0x00020000};
         };
+        const i32x4 rsP = mkrs(P, (int)(m.P * 4)), rsW1 = mkrs(P + m.o_w1, D * H1 * 4), rsX = mkrs(e.env_obs, e.n * D * 4),
+                    rsH = mkrs(g.pack + m.p_wht, 16 * H2 * 4), rsW2 = mkrs(g.pack + m.p_w2k, H1 * H2 * 4);
+#define BLD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
+#define BLD4(cls, dst, voff, rs, soff) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : cls(dst) : "v"(voff), "s"(rs), "s"(soff))
         const unsigned col = 64u * wave + lane;
         const unsigned cc1 = col < (unsigned)H1 ? col : (unsigned)H1 - 1u, cc2 = col < (unsigned)H2 ? col : (unsigned)H2 - 1u;
-        float x0;                                                            // element tid of the first tile's lx image
-        {
-            const int il = tid / sx, el = tid - il * sx, i = 4 * wg + il;
-            const bool ok = tid < 4 * sx && i < e.n && el < D;
-            const float v = e.env_obs[ok ? (long long)i * D + el : 0];
-            x0 = ok ? v : 0.0f;
-        }
-        // heads, from the fragment-ordered transposed shadow (dqn_net.hip: packed(WH^T), K = 1+A padded to 16, C = H2):
-        // float4 number ct*64 + ln holds WH^T[4j + (ln>>4)][16ct + (ln&15)], j = 0..3
-        const float4 *pwht = reinterpret_cast<const float4 *>(g.pack + m.p_wht);
-        const int nq4 = 4 * H2;
-        float4 whv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = tid + 256 * u; whv[u] = pwht[q < nq4 ? q : nq4 - 1]; }
-        // the slabs are read through descriptors that end with the matrix: rows past obs_dim / hidden1 (the zero padding
-        // of the size class) are out of range and come back as 0.0 from the bounds check, with no select in the way
-        const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + m.o_w1), 0, D * H1 * 4, 0x00020000);
-        float w1r[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            w1r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW1, (int)(cc1 * 4u), k * H1 * 4, 0));
-        float b1r = ldP(cc1, m.o_b1), b2r = ldP(cc2, m.o_b2);
         const int hr = lane & 3, hc = lane >> 2;                             // head chain of this lane (wave 0)
         const bool hlane = wave == 0 && hc <= A;
-        float bh = ldP((unsigned)((hc == 0 || hc > A) ? (int)m.o_bv : (int)m.o_ba + hc - 1), 0);
+        const int nq4 = 4 * H2;
+        // The W2 slab goes straight to its final registers as 16-B loads of the k-packed shadow (four consecutive k of
+        // the lane's column; measured 69 B/clk/CU against 36 for dword rows): k < 64 to architectural VGPRs, the rest to
+        // accumulation VGPRs (the ISA addresses 256 of each; the matrix core reads its B operand from either file; the
+        // compiler would stage every row in an architectural VGPR first: spills, serialised copies).
+        f32x4 w2q[4 * KB];
+        constexpr int N1 = 4 * KB < 32 ? 4 * KB : 32;          // first part of the slab; the rest follows the small operands
+        const int vw2 = (int)(cc2 * 16u);
+#pragma unroll
+        for (int kq = 0; kq < N1; ++kq) {
+            if (kq < 16) BLD4("=v", w2q[kq], vw2, rsW2, kq * H2 * 16); else BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
+        }
+        float x0, w1r[16], b1r, b2r, bh;
+        f32x4 whv[4];
+        int vx, v1, v2, vh, vq[4];
+        {
+            // element tid of the first tile's lx image (out of range => 0.0: padding columns, rows past n)
+            const int il = tid / sx, el = tid - il * sx, i = 4 * wg + il;
+            vx = (tid < 4 * sx && i < e.n && el < D) ? (i * D + el) * 4 : 0x7ffffff0;
+            BLD1(x0, vx, rsX, 0);
+            v1 = (int)(cc1 * 4u); v2 = (int)(cc2 * 4u);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) BLD1(w1r[k], v1, rsW1, k * H1 * 4);
+            BLD1(b1r, v1, rsP, (int)m.o_b1 * 4);
+            BLD1(b2r, v2, rsP, (int)m.o_b2 * 4);
+            vh = ((hc == 0 || hc > A) ? (int)m.o_bv : (int)m.o_ba + hc - 1) * 4;
+            BLD1(bh, vh, rsP, 0);
+            // heads, from the fragment-ordered transposed shadow (dqn_net.hip: packed(WH^T), K = 1+A padded to 16, C = H2):
+            // float4 number ct*64 + ln holds WH^T[4j + (ln>>4)][16ct + (ln&15)], j = 0..3
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { vq[u] = (tid + 256 * u) * 16; BLD4("=v", whv[u], vq[u], rsH, 0); }
+        }
+        // (the address registers of the requests above stay allocated until here: were one of them reused as a destination
+        // of the slab requests, the compiler would put a full wait in front of that request)
+        asm volatile("" :: "v"(vx), "v"(v1), "v"(v2), "v"(vh), "v"(vq[0]), "v"(vq[1]), "v"(vq[2]), "v"(vq[3]));
         float eps = e.st->epsilon;
         ASTAMP(20);
         // zero images: h1 / h2 columns past hidden1 / hidden2 and the heads' padding stay zero for the whole launch
@@ -202,42 +226,26 @@ k_actor(NetDims m, ActorArgs g) {
         if (tid < 3) lflag[tid] = 0;
         LDS_BARRIER();
         ASTAMP(21);
+        // the small operands are the youngest requests: everything issued so far has landed after this wait; the registers
+        // are operands of the wait (or of a pin right behind it) so that no use of them can be scheduled ahead of it
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(whv[0]), "+v"(whv[1]), "+v"(whv[2]), "+v"(whv[3]) :: "memory");
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
         // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int q = tid + 256 * u, ct = q >> 6, ln = q & 63, gq = ln >> 4, k = 16 * ct + (ln & 15);
             if (q < nq4) {
-                if (gq <= A) lwh[gq * s2 + k] = whv[u].x;
-                if (4 + gq <= A) lwh[(4 + gq) * s2 + k] = whv[u].y;
-                if (8 + gq <= A) lwh[(8 + gq) * s2 + k] = whv[u].z;
-                if (12 + gq <= A) lwh[(12 + gq) * s2 + k] = whv[u].w;
+                if (gq <= A) lwh[gq * s2 + k] = whv[u][0];
+                if (4 + gq <= A) lwh[(4 + gq) * s2 + k] = whv[u][1];
+                if (8 + gq <= A) lwh[(8 + gq) * s2 + k] = whv[u][2];
+                if (12 + gq <= A) lwh[(12 + gq) * s2 + k] = whv[u][3];
             }
         }
-        // first tile's rows; every compiler-tracked request above has now been waited for, so none of its waits can
-        // be held up by the untracked slab requests that follow
-        if (tid < 4 * sx) lx[tid] = x0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
-        asm volatile("" : "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(eps));
+        if (tid < 4 * sx) lx[tid] = x0;                                      // first tile's rows
         ASTAMP(22);
-        // The W2 slab goes straight to its final registers as 16-B loads of the k-packed shadow (four consecutive k of
-        // the lane's column; measured 69 B/clk/CU against 36 for dword rows): k < 64 to architectural VGPRs, the rest to
-        // accumulation VGPRs (the ISA addresses 256 of each; the matrix core reads its B operand from either file).
-        // Inline asm, because the compiler would stage every row in an architectural VGPR first (all live at once:
-        // spills, serialised copies); such loads are invisible to its wait insertion, hence the explicit s_waitcnt below.
-        f32x4 w2q[4 * KB];
-        {
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            const unsigned long long base = reinterpret_cast<unsigned long long>(g.pack + m.p_w2k);
-            const i32x4 rs = {(int)(unsigned)(base & 0xffffffffull), (int)(unsigned)(base >> 32), H1 * H2 * 4, 0x00020000};
-            const int voff = (int)(cc2 * 16u);
 #pragma unroll
-            for (int kq = 0; kq < 4 * KB; ++kq) {
-                const int soff = kq * H2 * 16;                               // rows past hidden1: out of range => 0.0
-                if (kq < 16) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w2q[kq]) : "v"(voff), "s"(rs), "s"(soff));
-                else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(w2q[kq]) : "v"(voff), "s"(rs), "s"(soff));
-            }
-        }
+        for (int kq = N1; kq < 4 * KB; ++kq) BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
         ASTAMP(23);
         // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
         const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
@@ -283,7 +291,7 @@ k_actor(NetDims m, ActorArgs g) {
                             }
                         }
                     } else {
-                        for (int k = 0; k < D; ++k) acc = MFMA1(ar[k], ldP(cc1, m.o_w1 + (long long)k * H1), acc);
+                        for (int k = 0; k < D; ++k) acc = MFMA1(ar[k], P[m.o_w1 + (long long)k * H1 + cc1], acc);
                     }
                     if (col < (unsigned)H1) {
 #pragma unroll
@@ -327,6 +335,11 @@ k_actor(NetDims m, ActorArgs g) {
                 LDS_BARRIER();
                 ASTAMP(3 + 4 * t);
                 if (wave == 0) {
+                    // everything of the policy lanes that does not depend on the forward pass, ahead of the chain (it then
+                    // issues in the chain's dependency stalls instead of after it)
+                    const int pil = lane < cnt ? lane : 0, pi = i0 + pil;
+                    long long pk = at + pil; if (pk >= e.cap) pk -= e.cap;
+                    int32_t *p_act = e.actions + pk; float *p_rew = e.rewards + pk; uint8_t *p_done = e.dones + pk;
                     // heads (dddqn.py:29-30): 4 rows x (1+A) columns = 4*(1+A) fmaf chains over hidden2, one per lane
                     if (hlane) {
                         const float *ar = l2 + hr * s2, *wr = lwh + hc * s2;
@@ -352,23 +365,36 @@ k_actor(NetDims m, ActorArgs g) {
                     }
                     if (t == 1) ASTAMP(25);
                     // the random draws of this step were made by waves 1..3 meanwhile
-                    while (lflag[0] != flagv || lflag[1] != flagv || lflag[2] != flagv) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order
+                    for (;;) {                                                    // one 16-B LDS read per poll
+                        asm volatile("" ::: "memory");                            // re-read
+                        const int4 fl = *reinterpret_cast<const int4 *>(lflag);
+                        if (fl.x == flagv && fl.y == flagv && fl.z == flagv) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                     if (t == 1) ASTAMP(26);
                     if (lane < cnt) {
                         // dueling combine (dddqn.py:31) + epsilon-greedy (q_agent.py:137-141, compute_action :70)
-                        const int il = lane, i = i0 + il;
-                        const float *hrow = lq + il * 16;
-                        float sum = 0.0f, qrow[16];
-                        for (int a = 0; a < A; ++a) sum = sum + hrow[1 + a];
+                        const int il = pil, i = pi;
+                        // (the 16 head outputs and the draws in registers after ONE LDS latency; unrolled, no indexed arrays)
+                        const float4 *hrow = reinterpret_cast<const float4 *>(lq + il * 16);
+                        const float4 h0 = hrow[0], h1 = hrow[1], h2 = hrow[2], h3 = hrow[3];
+                        const float4 dr = *reinterpret_cast<const float4 *>(lrand + il * 4);
+                        const float h[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < 15; ++a) if (a < A) sum = sum + h[1 + a];
                         const float mean = __fdiv_rn(sum, (float)A);
-                        for (int a = 0; a < A; ++a) qrow[a] = (hrow[0] + hrow[1 + a]) - mean;
                         int act = 0;
-                        for (int a = 1; a < A; ++a) if (qrow[a] > qrow[act]) act = a;
-                        if (!(eps < lrand[il * 4 + 0])) act = __float_as_int(lrand[il * 4 + 1]);
+                        float best = (h[0] + h[1]) - mean;
+#pragma unroll
+                        for (int a = 1; a < 15; ++a) {
+                            const float qa = (h[0] + h[1 + a]) - mean;
+                            if (a < A && qa > best) { best = qa; act = a; }          // first max wins (compute_action :70)
+                        }
+                        if (!(eps < dr.x)) act = __float_as_int(dr.y);
                         if (last) g.act_out[i] = act;
                         // the action-dependent part of the transition (q_agent.py:177-183)
-                        long long k = at + il; if (k >= e.cap) k -= e.cap;
+                        const long long k = pk;
                         if (e.kind == 1) {
                             float sv[4];
                             for (int j = 0; j < 4; ++j) { sv[j] = lx[il * sx + j]; e.states[k * 4 + j] = sv[j]; }
@@ -391,15 +417,16 @@ k_actor(NetDims m, ActorArgs g) {
                                 for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = sv[j];
                             }
                         } else {
-                            e.actions[k] = act;                                      // replay_buffer.py:60
-                            e.rewards[k] = lrand[il * 4 + 3];                        // :61
-                            e.dones[k] = lrand[il * 4 + 2] != 0.0f ? 1 : 0;          // :63
+                            *p_act = act;                                            // replay_buffer.py:60
+                            *p_rew = dr.w;                                           // :61
+                            *p_done = dr.z != 0.0f ? 1 : 0;                          // :63
                         }
                     }
                 } else {
                     // waves 1..3, meanwhile: every Philox draw of the step (none depends on the forward pass) -- the
                     // policy's (u, random action), and for the synthetic env the next observations (written to the ring
                     // and to the LDS state right here) and the (reward, done) pairs
+                    if (t == 1) WSTAMP(27);
                     const int nobs = e.kind == 0 ? cnt * D : 0;
                     for (int u = tid - 64; u < nobs + 2 * cnt; u += 192) {
                         if (u < nobs) {
@@ -427,7 +454,8 @@ k_actor(NetDims m, ActorArgs g) {
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes are done ...
-                    if (lane == 0) lflag[wave - 1] = flagv;                      // ... before its flag
+                    if (lane == 0) *reinterpret_cast<volatile int *>(lflag + (wave - 1)) = flagv;   // ... before its flag
+                    if (t == 1) WSTAMP(28);
                 }
                 LDS_BARRIER();
                 ASTAMP(4 + 4 * t);

@@ -49,6 +49,10 @@ def main():
     if st[7, 25, 0]:
         print(f"k_actor step 1 heads phase (cycles since its L2 done): chain done +{int(st[7, 25, 0] - st[7, 7, 0])}, "
               f"draw flags seen +{int(st[7, 26, 0] - st[7, 7, 0])}, policy + stores done +{int(st[7, 8, 0] - st[7, 7, 0])}")
+    if st[7, 27, 0]:
+        print(f"k_actor step 1, wave 1 (real-time ns since the step's L2 done): draws start {int(st[7, 27, 1] - st[7, 7, 1]) * 10}, "
+              f"flag written {int(st[7, 28, 1] - st[7, 7, 1]) * 10}; wave 0: chain done {int(st[7, 25, 1] - st[7, 7, 1]) * 10}, "
+              f"flags seen {int(st[7, 26, 1] - st[7, 7, 1]) * 10}, phase end {int(st[7, 8, 1] - st[7, 7, 1]) * 10}")
     for k, (name, labels) in NAMES.items():
         t = st[k, :len(labels)]
         cyc = t[:, 0] - t[0, 0]; real = (t[:, 1] - t[0, 1]) * 10.0     # ns
