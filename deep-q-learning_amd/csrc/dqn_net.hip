@@ -47,6 +47,13 @@ extern "C" int dqn_debug_stamps(unsigned long long *out_host) {
 __device__ __forceinline__ int perm16(int c) { return ((c & 3) << 2) | (c >> 2); }
 
 
+// position, in a batch-major packed [B x C] matrix (K = batch), of accumulator element r of this lane for the MFMA tile
+// (16-row batch tile `tile`, 16-column tile ct): pidx(KQb, 16*tile + 4*(lane>>4) + r, 16*ct + (lane&15)) with the
+// divisions and masks folded away
+__device__ __forceinline__ int pfrag(int KQb, int tile, int ct, int r, int lane) {
+    return (ct * KQb + tile) * 256 + r * 64 + ((lane & 15) << 2) + (lane >> 4);
+}
+
 NetDims make_dims(int D, int H1, int H2, int A) {
     NetDims m{};
     m.D = D; m.H1 = H1; m.H2 = H2; m.A = A;
@@ -191,6 +198,9 @@ struct MmaLayer {
             // single chunk; k-blocks [0, AHEAD) were requested by load_range<0, AHEAD>() long ago, block
             // p + AHEAD is requested right before block p is multiplied: the address traffic of the layer
             // is spread between the MFMAs instead of blocking the wave's issue in one burst
+            // the A fragment of k-block p + 1 is read from LDS before the MFMAs of block p (its latency hides behind them;
+            // past the last block the read lands in the row's padding and is not used)
+            float4 a_cur = *reinterpret_cast<const float4 *>(arow);
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
                 if (p < KQ) {
@@ -199,7 +209,8 @@ struct MmaLayer {
 #pragma unroll
                         for (int t = 0; t < TN; ++t) b0[p + AHEAD < PF ? p + AHEAD : 0][t] = pk[t][(long long)kq * 64];
                     }
-                    const float4 a4 = *reinterpret_cast<const float4 *>(arow + 16 * p);
+                    const float4 a4 = a_cur;
+                    if (p + 1 < PF) a_cur = *reinterpret_cast<const float4 *>(arow + (p + 1 < KQ ? 16 * (p + 1) : 0));
 #pragma unroll
                     for (int t = 0; t < TN; ++t) {
                         acc[t] = MFMA4(a4.x, b0[p][t].x, acc[t]);
@@ -207,6 +218,7 @@ struct MmaLayer {
                         acc[t] = MFMA4(a4.z, b0[p][t].z, acc[t]);
                         acc[t] = MFMA4(a4.w, b0[p][t].w, acc[t]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -277,7 +289,9 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
     }
     L2.init(ps.pack + m.p_w2, m.H1 / 16, m.H2 / 16, wave, lane);
-    L2.template load_range<0, 6>();                          // the first AHEAD k-blocks; the rest interleave with the MFMAs
+    // the first AHEAD k-blocks; the rest interleave with the MFMAs (requesting the whole layer here was measured equal:
+    // the issue burst delays x by what it saves later -- the 256 KB weight stream per workgroup is the bound either way)
+    L2.template load_range<0, 6>();
     if (wave == 0) LH.init(ps.pack + m.p_wh, m.H2 / 16, 1, 0, lane);
     if (sampling && !presampled) {
         // the weight requests above are in flight; now the dependent tree descent, then the gathered rows
@@ -319,7 +333,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         for (int t = 0; t < TN1; ++t) {
             const int ct = wave + 4 * t;
             if (ct < m.H1 / 16) {
-                const int c = lane & 15, col = 16 * ct + c;
+                const int c = lane & 15;
                 const float bias = bias1[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -327,7 +341,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
                     float v = acc[t][r] + bias;
                     v = v > 0.0f ? v : 0.0f;
                     l1[rl * s1 + 16 * ct + perm16(c)] = v;
-                    if (ps.ph1) ps.ph1[pidx(KQb, row0 + rl, col)] = v;
+                    if (ps.ph1) ps.ph1[pfrag(KQb, tile, ct, r, lane)] = v;
                 }
             }
         }
@@ -353,7 +367,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
                     float v = acc[t][r] + bias;
                     v = v > 0.0f ? v : 0.0f;
                     l2[rl * s2 + 16 * ct + perm16(c)] = v;
-                    if (ps.ph2) ps.ph2[pidx(KQb, row0 + rl, col)] = v;
+                    if (ps.ph2) ps.ph2[pfrag(KQb, tile, ct, r, lane)] = v;
                     if (ps.feat && row0 + rl < B) ps.feat[(long long)(row0 + rl) * m.H2 + col] = v;   // :32-33
                 }
             }
@@ -501,7 +515,6 @@ template <int TN1, int TN2>
 __global__ void __launch_bounds__(256)
 k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[256];
     const int tile = blockIdx.x, row0 = tile * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int KQb = (B + 15) / 16;
@@ -536,7 +549,14 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
     for (int t = 0; t < TN2; ++t) {
         int ct = wave + 4 * t; ct = ct < m.H2 / 16 ? ct : m.H2 / 16 - 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m2[t][r] = g.ph2[pidx(KQb, row0 + 4 * (lane >> 4) + r, 16 * ct + (lane & 15))];
+        for (int r = 0; r < 4; ++r) m2[t][r] = g.ph2[pfrag(KQb, tile, ct, r, lane)];
+    }
+    // the layer-1 ReLU gates and the first k-blocks of W2^T are requested now: they stream in behind the TD arithmetic
+#pragma unroll
+    for (int t = 0; t < TN1; ++t) {
+        int ct = wave + 4 * t; ct = ct < m.H1 / 16 ? ct : m.H1 / 16 - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m1[t][r] = g.ph1[pfrag(KQb, tile, ct, r, lane)];
     }
     LB.init(g.pack + m.p_w2t, m.H2 / 16, m.H1 / 16, wave, lane);
     LB.template load_range<0, 6>();
@@ -596,23 +616,16 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
         for (int t = 0; t < TN2; ++t) {
             const int ct = wave + 4 * t;
             if (ct < m.H2 / 16) {
-                const int c = lane & 15, col = 16 * ct + c;
+                const int c = lane & 15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rl = 4 * (lane >> 4) + r;
                     const float v = m2[t][r] > 0.0f ? acc[t][r] : 0.0f;
                     l2[rl * s2 + 16 * ct + perm16(c)] = v;
-                    g.pdz2[pidx(KQb, row0 + rl, col)] = v;
+                    g.pdz2[pfrag(KQb, tile, ct, r, lane)] = v;
                 }
             }
         }
-    }
-    // the layer-1 ReLU gates (the rest of W2^T is requested between the MFMAs below)
-#pragma unroll
-    for (int t = 0; t < TN1; ++t) {
-        int ct = wave + 4 * t; ct = ct < m.H1 / 16 ? ct : m.H1 / 16 - 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m1[t][r] = g.ph1[pidx(KQb, row0 + 4 * (lane >> 4) + r, 16 * ct + (lane & 15))];
     }
     LDS_BARRIER();
     STAMP(5, 3);
@@ -625,11 +638,9 @@ k_bwd_rows(NetDims m, BwdArgs g, int B, DqnState *st) {
         for (int t = 0; t < TN1; ++t) {
             const int ct = wave + 4 * t;
             if (ct < m.H1 / 16) {
-                const int c = lane & 15, col = 16 * ct + c;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int rl = 4 * (lane >> 4) + r;
-                    g.pdz1[pidx(KQb, row0 + rl, col)] = m1[t][r] > 0.0f ? acc[t][r] : 0.0f;
+                    g.pdz1[pfrag(KQb, tile, ct, r, lane)] = m1[t][r] > 0.0f ? acc[t][r] : 0.0f;
                 }
             }
         }
@@ -758,11 +769,18 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
             }
     };
     load(a0, c0, k0);
-    for (int kq0 = k0; kq0 < k1; kq0 += 2 * PF) {
-        load(a1, c1, kq0 + PF);
-        compute(a0, c0, kq0);
-        load(a0, c0, kq0 + 2 * PF);
-        compute(a1, c1, kq0 + PF);
+    if (per <= 2 * PF) {
+        // the wave's whole batch slice in one round trip (B <= 1024): both chunks requested before the first MFMA
+        load(a1, c1, k0 + PF);
+        compute(a0, c0, k0);
+        compute(a1, c1, k0 + PF);
+    } else {
+        for (int kq0 = k0; kq0 < k1; kq0 += 2 * PF) {
+            load(a1, c1, kq0 + PF);
+            compute(a0, c0, kq0);
+            load(a0, c0, kq0 + 2 * PF);
+            compute(a1, c1, kq0 + PF);
+        }
     }
     STAMP(6, 1);
 #pragma unroll
@@ -796,7 +814,13 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
                 if (ad.adamw) u = u + (ad.wd * pnew);
                 pnew = pnew + (co.neglr * u);
                 ad.P[i] = pnew;
-                scatter_packs(m, i, pnew, ad.pack);
+                if (e == 0 && which == 2) {
+                    // a W2 tile element knows its (k, n): the three shadows without the index divisions of scatter_packs
+                    const int k = 16 * mt + (tid >> 4), n = 16 * nt + (tid & 15);
+                    ad.pack[m.p_w2 + pidx(m.H1 / 16, k, n)] = pnew;
+                    ad.pack[m.p_w2t + pidx(m.H2 / 16, n, k)] = pnew;
+                    ad.pack[m.p_w2k + ((long long)(k >> 2) * m.H2 + n) * 4 + (k & 3)] = pnew;
+                } else scatter_packs(m, i, pnew, ad.pack);
             }
         }
     }
