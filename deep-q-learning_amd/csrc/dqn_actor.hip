@@ -126,8 +126,18 @@ k_actor(NetDims m, ActorArgs g) {
         BSTAMP(1);
         const float pmax = e.st->pmax;
         const long long a = (long long)(c0 % (unsigned long long)e.cap);
-        if (nT <= RANGE_MAX && a + (long long)nT <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, (int)nT, pmax, lds);
-        else per_add_slow(e.tree, e.Nt, e.L, c0, (int)nT, pmax, e.cap);
+        // the new slots are one contiguous leaf range, or two when the ring wraps; each is inserted in pieces of at most
+        // RANGE_MAX leaves (the LDS budget of per_add_range_wg). Any order gives the same tree: a parent is always the
+        // sum of its two current children.
+        for (int seg = 0; seg < 2; ++seg) {
+            const long long s0 = seg == 0 ? a : 0;
+            const long long s1 = seg == 0 ? (a + (long long)nT < e.cap ? a + (long long)nT : e.cap) : a + (long long)nT - e.cap;
+            for (long long off = s0; off < s1; off += RANGE_MAX) {
+                const int cnt = (int)(s1 - off < RANGE_MAX ? s1 - off : RANGE_MAX);
+                per_add_range_wg(e.tree, e.Nt, e.L, off, cnt, pmax, lds);
+                __syncthreads();                                             // this workgroup's tree stores, before it re-reads them
+            }
+        }
         BSTAMP(2);
         if (g.n_smp > 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // each thread: its tree stores
@@ -505,7 +515,7 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
                                   (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 16 + 4);
     if (g.n_tree) {
         const size_t nT = (size_t)T * (size_t)env.n;
-        size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : 0) + 2) + 64);
+        size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : RANGE_MAX) + 2) + 64);
         if (lds < need) lds = need;
         if (env.rebuild_top) { need = sizeof(float) * ((size_t)1 << (env.L < PW_TOP ? env.L : PW_TOP)); if (lds < need) lds = need; }
     }

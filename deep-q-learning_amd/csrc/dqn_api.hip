@@ -724,38 +724,57 @@ extern "C" int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_en
     });
 }
 
-/* n_iters x (env_steps vector env steps + one update) as ONE graph launch */
+/* n_iters x (env_steps vector env steps + one update) as ONE graph launch. With a communicator (dqn_comm_init) every
+ * update is: backward half -> in-place RCCL sum all-reduce of the flat gradient, captured in the same graph -> optimizer */
 extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps, int32_t n_envs, int32_t B,
                                void *stream) {
     int rc = check_B(h, B); if (rc) return rc;
     REQUIRE(n_iters >= 1 && n_iters <= 256 && env_steps >= 0 && env_steps <= 64, "n_iters / env_steps out of range");
     REQUIRE(env_steps == 0 || (n_envs >= 1 && n_envs <= h->cfg.max_batch && n_envs <= h->cfg.capacity),
             "n_envs=%d exceeds max_batch=%d or capacity", n_envs, h->cfg.max_batch);
-    if (h->world != 1) return fail(DQN_ERR_STATE, "dqn_train_iters is the single-GPU path; with world_size > 1 use "
-                                                  "dqn_actor_step + dqn_update_backward / all-reduce / dqn_update_apply");
+    if (h->world != 1 && !h->comm)
+        return fail(DQN_ERR_STATE, "dqn_train_iters with world_size > 1 needs dqn_comm_init (the all-reduce is captured in the "
+                                   "graph); without a communicator use dqn_actor_backward / your all-reduce / dqn_update_apply");
     hipStream_t st = (hipStream_t)stream;
+    const bool dp = h->comm != nullptr;                                   // also a 1-rank communicator (rehearsal)
     const std::vector<int> key{n_iters, env_steps, n_envs, B};
-    return run_captured(h, &h->loop_graphs[key], st, [&] {
-        // Inside the loop the rebuild of the tree top after an update is deferred into the FIRST actor launch of the
-        // next iteration (its surplus workgroup is the next reader and has slack); the last update keeps k_per_top so
-        // that the tree is consistent when the graph ends.
-        // (measured: +4.8 % on the f32 path whose actor forward is long enough to hide it, -1 % on bf16: f32 only)
+    int comm_err = 0;
+    rc = run_captured(h, &h->loop_graphs[key], st, [&] {
+        // one update: single learner = everything fused into the dW launch; data-parallel = backward half (with the
+        // PER write-back), the gradient all-reduce, the optimizer
+        auto update = [&](bool defer_top, bool presampled) {
+            if (!dp) { enqueue_update(h, B, st, st && !h->profiling, defer_top, presampled); return; }
+            enqueue_backward(h, B, st, false, true, defer_top, presampled);
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;                       // profiling: the collective is not one of our launches
+            if (h->profiling) { arm(h); ev0 = g_prof_ev0; ev1 = g_prof_ev1; g_prof_ev0 = nullptr; g_prof_ev1 = nullptr; }
+            if (ev0) (void)hipEventRecord(ev0, st);
+            const int e = g_rccl.AllReduce(h->grad, h->grad, (size_t)h->m.P, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, st);
+            if (e) comm_err = e;
+            if (ev1) (void)hipEventRecord(ev1, st);
+            mark(h, st, "allreduce");
+            enqueue_apply(h, B, st);
+        };
+        // Inside the loop the rebuild of the tree top after an update is deferred into the actor launch of the next
+        // iteration (its tree workgroup is the next reader and has slack); the last update keeps k_per_top so that the
+        // tree is consistent when the graph ends.
         bool can_defer = env_steps > 0 && h->cfg.use_per;
         if (env_steps > 0 && actor_multi_ok(h, n_envs, env_steps)) {
-            // f32: the env_steps actor steps of an iteration are ONE launch, which also inserts their leaves and draws
-            // the update's PER batch on side workgroups
+            // the env_steps actor steps of an iteration are ONE launch, which also inserts their leaves and draws the
+            // update's PER batch on side workgroups
             for (int it = 0; it < n_iters; ++it) {
                 enqueue_actor_multi(h, env_steps, n_envs, st, can_defer && it > 0, B);
-                enqueue_update(h, B, st, st && !h->profiling, can_defer && it + 1 < n_iters, h->cfg.use_per != 0);
+                update(can_defer && it + 1 < n_iters, h->cfg.use_per != 0);
             }
             return;
         }
         can_defer = can_defer && !h->bf16;                            // (per-step bf16 actor launches: measured -1 %)
         for (int it = 0; it < n_iters; ++it) {
             for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st, can_defer && it > 0 && e == 0);
-            enqueue_update(h, B, st, st && !h->profiling, can_defer && it + 1 < n_iters);
+            update(can_defer && it + 1 < n_iters, false);
         }
     });
+    if (comm_err) return fail(DQN_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(comm_err) : "?");
+    return rc;
 }
 
 extern "C" int dqn_sync_target(dqn_handle *h, void *stream) {

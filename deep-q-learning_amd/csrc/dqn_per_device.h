@@ -251,8 +251,10 @@ __device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int 
     const long long first = Nt + a, last = Nt + a + n - 1;
     for (int l = tid; l < L; l += nt) {
         const long long lo = first >> l, hi = last >> l;
-        bl[l] = (lo & 1) ? tree[lo - 1] : 0.0f;
-        br[l] = (hi & 1) ? 0.0f : tree[hi + 1];
+        // (L1-bypassing loads: a previous piece of the same insert, run by this workgroup, may have written these nodes
+        // after this CU's L1 cached their lines)
+        bl[l] = (lo & 1) ? __hip_atomic_load(&tree[lo - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        br[l] = (hi & 1) ? 0.0f : __hip_atomic_load(&tree[hi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int j = tid; j < n; j += nt) { v0[j] = pmax; tree[first + j] = pmax; }
     LDS_BARRIER();

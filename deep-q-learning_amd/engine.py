@@ -339,6 +339,25 @@ class Engine:
         graph launch; then all-reduce DQN_BUF_GRAD and call update_apply"""
         L.check(self.lib.dqn_actor_backward(self.h, env_steps, getattr(self, "n_envs", 0), B, self._s(stream)))
 
+    # ------------------------------------------------------------- native RCCL
+    def comm_init_native(self):
+        """create the handle's own RCCL communicator (dqn_comm_init): rank 0 makes the unique id, torch.distributed
+        carries it to the other ranks. Afterwards train_iters captures the gradient all-reduce inside its graph."""
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            L.check(self.lib.dqn_comm_unique_id(uid))
+        if world > 1:
+            dev = self.device if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(list(uid.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        L.check(self.lib.dqn_comm_init(self.h, uid, rank, world))
+
+    def allreduce_grads_native(self, stream=None):
+        L.check(self.lib.dqn_allreduce_grads(self.h, self._s(stream)))
+
     # ------------------------------------------------------------------ profiling
     def profile_begin(self, stream=None):
         L.check(self.lib.dqn_profile_begin(self.h, self._s(stream)))

@@ -356,7 +356,8 @@ def test_actor_step_bitexact(dq, per):
     ((8, 256, 256, 4), 256, 4, 11, True),    # the bench shape
     ((20, 48, 80, 3), 10, 5, 7, True),       # obs_dim > 16: layer-1 weights streamed per step; odd hidden sizes
     ((70, 16, 16, 2), 5, 2, 6, True),        # obs_dim > 60: tile rows span more than 256 LDS elements
-    ((4, 64, 64, 2), 1030, 4, 13, True),     # more tiles than actor workgroups (tile loop), T*n beyond the LDS range insert
+    ((4, 64, 64, 2), 1030, 4, 13, True),     # more tiles than actor workgroups (tile loop)
+    ((4, 16, 16, 2), 3000, 3, 14, True),     # T*n = 9000 leaves: range insert in pieces, and in two segments on the wrap
 ])
 def test_actor_steps_one_launch_bitexact(dq, dims, n, T, L_, per):
     """dqn_actor_steps: T vector env steps in ONE launch (k_actor) must leave exactly what T sequential oracle actor
@@ -416,9 +417,12 @@ def test_profile_hooks_and_error_paths(dq):
     e.close(); u.close()
 
 
-def test_train_iters_one_graph_matches_oracle(dq):
+@pytest.mark.parametrize("native_comm", [False, True])
+def test_train_iters_one_graph_matches_oracle(dq, native_comm):
     """the reference's inner loop (q_agent.py:174-187) captured as ONE graph: 3 iterations of
-    (4 vector env steps + 1 update), replayed twice, vs the oracle stepping the same loop."""
+    (4 vector env steps + 1 update), replayed twice, vs the oracle stepping the same loop. native_comm: the
+    data-parallel form of the graph (backward half -> RCCL all-reduce captured in the graph -> optimizer) with a
+    one-rank communicator, which must leave the same result."""
     import torch
     dims = CFGS["cfg1"]
     D = dims[0]
@@ -434,6 +438,8 @@ def test_train_iters_one_graph_matches_oracle(dq):
     lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 91, beta=0.4)
     obs = np.random.default_rng(94).standard_normal((n, D)).astype(np.float32)
     e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
+    if native_comm:
+        e.comm_init_native()
     ctr = 0
     for _ in range(6):
         for _ in range(4):

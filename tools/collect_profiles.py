@@ -21,16 +21,16 @@ with open(f"profiles/{rnd}_kernel_stats.csv", "w", newline="") as o:
 f = glob.glob(f"gpurun_out/prof_{tag}/*/*kernel_trace.csv")[0]
 tr = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("k_", "void k_"))]
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-# one inner-loop iteration of the f32 loop: 4 actor launches, then sample+forward x3, bwd_rows, dw (+ per_top)
+# two inner-loop iterations of the f32 loop inside a graph: k_actor (4 vector env steps + leaves + next batch's PER draw),
+# k_qnet_fwd (gather + 3 passes), k_bwd_rows, k_dw (+ Adam + priority write-back)
 i0 = len(tr) // 3
-while not ("k_bwd_rows<" in tr[i0]["Kernel_Name"] and "fwd<" in tr[i0 - 1]["Kernel_Name"]):
+while "k_actor" not in tr[i0]["Kernel_Name"]:
     i0 += 1
-i0 -= 5
 with open(f"profiles/{rnd}_kernel_trace_one_step.csv", "w", newline="") as o:
     w = csv.writer(o)
     w.writerow(["kernel", "start_ns_rel", "duration_ns", "grid", "workgroup", "lds_bytes"])
     t0 = int(tr[i0]["Start_Timestamp"])
-    for r in tr[i0:i0 + 9]:
+    for r in tr[i0:i0 + 8]:
         w.writerow([r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]) - t0,
                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"]])
 for src, dst in ((f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc.json"),

@@ -65,11 +65,25 @@ def main():
             r["grads_us"] = t * 1e6; r["grads_TFs"] = (F + bk) * B / t / 1e12          # 1 fwd + bwd
             rows.append(r)
             print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
+    # k_actor (4 vector env steps per launch) over the number of envs: 4-env tiles, <= 255 actor workgroups
+    actor_rows = []
+    eng.close()
+    for ln in range(8, 17, 2):
+        n = 1 << ln
+        eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << L, use_per=True,
+                                        max_batch=max(n, 1024), seed=3))
+        eng.set_params(torch.randn(eng.param_count) * 0.05)
+        eng.env_reset(torch.randn(n, D, device=eng.device), 0.01); eng.set_epsilon(0.15)
+        with torch.cuda.stream(eng.stream):
+            t = timed(lambda: eng.actor_steps(4, eng.stream), max(5, min(200, (1 << 20) // n)), eng.stream)
+        r = {"n_envs": n, "actor_steps4_us": t * 1e6, "env_steps_per_s": 4 * n / t, "TFs": 4 * n * F / t / 1e12}
+        actor_rows.append(r)
+        print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
+        eng.close()
     out = {"config": {"D": D, "H1": H1, "H2": H2, "A": A, "log2N": L, "dtype": "f32"},
-           "peaks": {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3}, "rows": rows}
+           "peaks": {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3}, "rows": rows, "actor_rows": actor_rows}
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
-    eng.close()
 
 
 if __name__ == "__main__":
