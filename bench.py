@@ -77,6 +77,13 @@ PMC_KEYS = {   # bench kernel label -> (kernel name in profiles/*_pmc.json, FETC
 }
 
 
+KERNEL_OF = {   # bench label -> kernel (symbol in the rocprofv3 summaries under profiles/)
+    "actor_steps": "k_actor (4 vector env steps of 256 envs in one launch + leaf insert + the next batch's PER draw)",
+    "td_bwd_rows": "k_bwd_rows", "dw_adam_perwrite": "k_dw (+ Adam + PER write-back)", "dw_perwrite": "k_dw (+ PER write-back)",
+    "dw_adam": "k_dw (+ Adam)", "dw": "k_dw", "per_top": "k_per_top", "adam": "k_adam", "allreduce": "RCCL all-reduce",
+}
+
+
 def pmc_traffic(label):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None"""
     import glob
@@ -370,7 +377,7 @@ def main():
         tr = [pmc_traffic(k) for k in ks]
         roof = {"bound": bound, "achieved": ach, "peak": peak, "unit": per_step[ks[0]]["unit"], "frac": ach / peak,
                 "traffic": (sum(t * per_step[k]["launches_per_step"] for t, k in zip(tr, ks)) / nl) if all(t is not None for t in tr) else None,
-                "kernel": dom + (f" (per step: {fwd_shapes}; per-shape lines under \"kernels\")" if dom == "k_qnet_fwd" else ""),
+                "kernel": KERNEL_OF.get(dom, dom) + (f" (per step: {fwd_shapes}; per-shape lines under \"kernels\")" if dom == "k_qnet_fwd" else ""),
                 "avg_us": gtime[dom] / nl, "launches_per_step": nl,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r*_pmc.json, bytes per launch",
                 "timing": "hipExtLaunchKernelGGL start/stop events of each eager launch on the launch stream, median of "
