@@ -25,7 +25,7 @@ class DqnConfig(C.Structure):
                 ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("gamma", C.c_float),
                 ("per_alpha", C.c_float), ("per_eps", C.c_float), ("per_beta", C.c_float),
                 ("precision", C.c_int32), ("seed", C.c_uint64), ("world_size", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("n_step", C.c_int32)]
 
 
 _P, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float

@@ -102,6 +102,41 @@ __device__ __forceinline__ void presample_tile(const SampleArgs &s, int row0, in
     }
 }
 
+// ---- n-step returns (dqn_config.n_step > 1). History rows are re-read by the thread that wrote them, n_step - 1 steps
+// later in the same launch: L1-bypassing loads, because this CU's L1 may still hold the line from the previous read.
+template <class T> __device__ __forceinline__ T ld_sc1(const T *p) {
+    return __hip_atomic_load(const_cast<T *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// files (action, reward, done) of env i at history slot hpos and, when the window is complete, replaces them by the row of
+// the window that starts at slot hold: its first action, R = r_0 + gamma*(r_1 + gamma*(...)) cut after the first done, and
+// that done flag (Horner form, one rounding per operation: the CPU restatement's arithmetic)
+__device__ __forceinline__ void nstep_row(const EnvArgs &e, int ns, int hpos, int hold, int i, bool emit, int &a, float &r, int &d) {
+    const long long hs = e.hist_stride;
+    e.hist_a[hpos * hs + i] = a; e.hist_r[hpos * hs + i] = r; e.hist_d[hpos * hs + i] = d;
+    if (!emit) return;
+    float rr[8]; int dd[8];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {                                        // the ns-1 older steps; the newest is in registers
+        const int p = hold + k < ns ? hold + k : hold + k - ns;
+        rr[k] = k < ns - 1 ? ld_sc1(e.hist_r + p * hs + i) : 0.0f;
+        dd[k] = k < ns - 1 ? ld_sc1(e.hist_d + p * hs + i) : 0;
+    }
+    const int a0 = ld_sc1(e.hist_a + hold * hs + i);
+    int last = ns - 1;
+#pragma unroll
+    for (int k = 6; k >= 0; --k) if (k < ns - 1 && dd[k]) last = k;      // first done in the window
+    float acc = last == ns - 1 ? r : 0.0f;
+    int dn = last == ns - 1 ? d : 1;
+#pragma unroll
+    for (int k = 6; k >= 0; --k) {
+        if (k < ns - 1) {
+            if (k == last) acc = rr[k];
+            else if (k < last) acc = rr[k] + e.gamma * acc;
+        }
+    }
+    a = a0; r = acc; d = dn;
+}
+
 // KB = 16-row k-blocks of the register-resident W2 slab: hidden1 <= 16*KB (columns / rows past hidden1 are zeros, and
 // x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
 // KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
@@ -112,7 +147,13 @@ k_actor(NetDims m, ActorArgs g) {
     const EnvArgs &e = g.env;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
-    const unsigned long long nT = (unsigned long long)g.T * (unsigned long long)e.n, c1 = c0 + nT;
+    // n-step returns: a vector step adds rows only once n_step steps are on file, i.e. not during the first `warm` steps
+    // after dqn_env_reset (n_step == 1: warm = 0, every step adds its n rows)
+    const unsigned long long hs0 = e.n_step > 1 ? e.st->hist_steps : 0ull;
+    const int warm = (e.n_step > 1 && hs0 + 1ull < (unsigned long long)e.n_step) ? (int)((unsigned long long)e.n_step - 1ull - hs0) : 0;
+    const int n_emit = g.T > warm ? g.T - warm : 0;
+    const unsigned long long nT = (unsigned long long)n_emit * (unsigned long long)e.n, c1 = c0 + nT;
+    const unsigned long long ticket_val = ec + (unsigned long long)g.T;   // flag value of THIS launch (the env step counter only grows)
     const unsigned total_wgs = gridDim.x;
     int role = 1, wg = (int)blockIdx.x - g.n_tree;
     if ((int)blockIdx.x < g.n_tree) role = 0;
@@ -142,14 +183,14 @@ k_actor(NetDims m, ActorArgs g) {
         if (g.n_smp > 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // each thread: its tree stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(&e.st->tree_ready, c1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(&e.st->tree_ready, ticket_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         BSTAMP(3);
     } else if (role == 2) {
         // ---- sampler workgroup: q_agent.py:147-153 for the update that follows this launch
         if (wg == 0) BSTAMP(4);
         if (tid == 0)
-            while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != c1)
+            while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket_val)
                 __builtin_amdgcn_s_sleep(4);
         if (wg == 0) BSTAMP(5);
         __syncthreads();
@@ -276,7 +317,11 @@ k_actor(NetDims m, ActorArgs g) {
             for (int t = 0; t < g.T; ++t) {
                 const bool last = t == g.T - 1;
                 const unsigned long long ect = ec + (unsigned long long)t;
-                const long long at = a0 + (long long)t * e.n + i0;              // slot of the tile's first env, before the wrap
+                const bool emit = t >= warm;                                    // (n-step warm-up: the step is only filed)
+                const long long at = a0 + (long long)(emit ? t - warm : 0) * e.n + i0;   // slot of the tile's first env, before the wrap
+                const int ns = e.n_step;
+                const int hpos = ns > 1 ? (int)((hs0 + (unsigned long long)t) % (unsigned long long)ns) : 0;   // history slot of this step
+                const int hold = ns > 1 ? (hpos + 1) % ns : 0;                                                 // oldest step of the window
                 const int flagv = (tile - wg) / g.G * g.T + t + 1;              // value the draw flags take in this step
                 // The slabs live in registers for the whole launch: the empty asm makes their values opaque here, so
                 // the compiler can neither re-request them from memory inside the step loop nor forget them.
@@ -406,13 +451,24 @@ k_actor(NetDims m, ActorArgs g) {
                         // the action-dependent part of the transition (q_agent.py:177-183)
                         const long long k = pk;
                         if (e.kind == 1) {
-                            float sv[4];
-                            for (int j = 0; j < 4; ++j) { sv[j] = lx[il * sx + j]; e.states[k * 4 + j] = sv[j]; }
+                            float sv[4], s0v[4];
+                            for (int j = 0; j < 4; ++j) { sv[j] = lx[il * sx + j]; s0v[j] = sv[j]; }
                             const bool term = cartpole_step(sv, act);
                             const int tt = lt[il] + 1;
                             const bool done = term || tt >= e.max_steps;             // q_agent.py:179-180
-                            for (int j = 0; j < 4; ++j) e.observations[k * 4 + j] = sv[j];
-                            e.actions[k] = act; e.rewards[k] = term ? e.term_reward : 1.0f; e.dones[k] = done ? 1 : 0;
+                            float rew = term ? e.term_reward : 1.0f;
+                            int a_row = act, d_row = done ? 1 : 0;
+                            if (ns > 1) {
+                                for (int j = 0; j < 4; ++j) {
+                                    e.hist_s[((long long)hpos * e.hist_stride + i) * 4 + j] = s0v[j];
+                                    if (emit) s0v[j] = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * 4 + j);
+                                }
+                                nstep_row(e, ns, hpos, hold, i, emit, a_row, rew, d_row);
+                            }
+                            if (emit) {
+                                for (int j = 0; j < 4; ++j) { e.states[k * 4 + j] = s0v[j]; e.observations[k * 4 + j] = sv[j]; }
+                                e.actions[k] = a_row; e.rewards[k] = rew; e.dones[k] = d_row ? 1 : 0;
+                            }
                             if (done) {
                                 atomicAdd(&e.st->ep_count, 1ull);
                                 atomicAdd(&e.st->ep_steps, (unsigned long long)tt);
@@ -427,9 +483,14 @@ k_actor(NetDims m, ActorArgs g) {
                                 for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = sv[j];
                             }
                         } else {
-                            *p_act = act;                                            // replay_buffer.py:60
-                            *p_rew = dr.w;                                           // :61
-                            *p_done = dr.z != 0.0f ? 1 : 0;                          // :63
+                            int a_row = act, d_row = dr.z != 0.0f ? 1 : 0;
+                            float rew = dr.w;
+                            if (ns > 1) nstep_row(e, ns, hpos, hold, i, emit, a_row, rew, d_row);
+                            if (emit) {
+                                *p_act = a_row;                                      // replay_buffer.py:60
+                                *p_rew = rew;                                        // :61
+                                *p_done = d_row ? 1 : 0;                             // :63
+                            }
                         }
                     }
                 } else {
@@ -444,8 +505,15 @@ k_actor(NetDims m, ActorArgs g) {
                             long long k = at + il; if (k >= e.cap) k -= e.cap;
                             const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
                             const float nx = ih_normal(o);
-                            e.states[k * D + el] = lx[il * sx + el];                 // replay_buffer.py:59
-                            e.observations[k * D + el] = nx;                         // :62
+                            float s_row = lx[il * sx + el];
+                            if (ns > 1) {                                            // n-step: the row starts at the oldest step on file
+                                e.hist_s[((long long)hpos * e.hist_stride + i) * D + el] = s_row;
+                                if (emit) s_row = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * D + el);
+                            }
+                            if (emit) {
+                                e.states[k * D + el] = s_row;                        // replay_buffer.py:59
+                                e.observations[k * D + el] = nx;                     // :62
+                            }
                             lx[il * sx + el] = nx;                                   // q_agent.py:183 (read by this thread only)
                             if (last) e.env_obs[(long long)i * D + el] = nx;
                         } else if (u < nobs + cnt) {
@@ -483,6 +551,7 @@ k_actor(NetDims m, ActorArgs g) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
             e.st->env_ctr = ec + (unsigned long long)g.T;
+            if (e.n_step > 1) e.st->hist_steps = hs0 + (unsigned long long)g.T;
             e.st->arrive = 0;
         }
     }

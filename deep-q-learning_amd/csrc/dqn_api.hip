@@ -81,6 +81,8 @@ struct dqn_handle {
     float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
+    float *hist_s = nullptr, *hist_r = nullptr; int32_t *hist_a = nullptr, *hist_d = nullptr;   // n-step history
+    int n_step = 1; float gamma_n = 0.0f;
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
@@ -145,6 +147,9 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(cfg->precision == DQN_PREC_F32 || cfg->precision == DQN_PREC_BF16, "unknown precision %d", cfg->precision);
     REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
     REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
+    REQUIRE(cfg->n_step >= 0 && cfg->n_step <= 8, "n_step %d out of range [0,8]", cfg->n_step);
+    REQUIRE(cfg->n_step <= 1 || cfg->capacity >= 64ll * cfg->max_batch, "n_step > 1 needs capacity >= 64 * max_batch "
+            "(the n-step actor runs in k_actor only, whose steps of one launch must fit the ring)");
 
     dqn_handle *h = new (std::nothrow) dqn_handle();
     if (!h) return fail(DQN_ERR_NOMEM, "host allocation failed");
@@ -152,6 +157,9 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->m = make_dims(D, H1, H2, A);
     h->world = cfg->world_size;
     h->bf16 = cfg->precision == DQN_PREC_BF16;
+    h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
+    h->gamma_n = cfg->gamma;
+    for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
     h->Bp = h->bf16 ? (cfg->max_batch + 31) / 32 * 32 : (cfg->max_batch + 15) / 16 * 16;
     if (cfg->use_per) {
         int L = 0; while ((1ll << L) < cfg->capacity) ++L;
@@ -186,6 +194,10 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
     add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp); add(&h->env_t, Bp * 4);
+    if (h->n_step > 1) {
+        const size_t ns = (size_t)h->n_step;
+        add(&h->hist_s, ns * Bp * D * 4); add(&h->hist_r, ns * Bp * 4); add(&h->hist_a, ns * Bp * 4); add(&h->hist_d, ns * Bp * 4);
+    }
     size_t total = 0;
     for (auto &it : items) total += align_up(it.bytes, 256);
     hipError_t e = hipMalloc(&h->arena, total);
@@ -511,7 +523,8 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
     BwdArgs g{};
     g.q = h->q; g.nq = h->nq; g.nt = h->nt; g.a = h->ba; g.r = h->br; g.d_u8 = h->bd;
-    g.w_raw = h->cfg.use_per ? h->bw_raw : nullptr; g.gamma = h->cfg.gamma;
+    g.w_raw = h->cfg.use_per ? h->bw_raw : nullptr;
+    g.gamma = h->n_step > 1 ? h->gamma_n : h->cfg.gamma;       // rows of the n-step actor bootstrap with gamma^n
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
@@ -558,6 +571,8 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
     e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
     e.kind = h->env_kind; e.max_steps = h->env_max_steps; e.env_t = h->env_t; e.term_reward = h->env_term_reward;
     e.rebuild_top = (rebuild_top && h->cfg.use_per) ? 1 : 0;
+    e.n_step = h->n_step; e.hist_stride = h->Bp; e.gamma = h->cfg.gamma;
+    e.hist_s = h->hist_s; e.hist_r = h->hist_r; e.hist_a = h->hist_a; e.hist_d = h->hist_d;
     return e;
 }
 
@@ -584,6 +599,7 @@ static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuil
     // ONE launch: forward + epsilon-greedy policy (:176), then per workgroup the synthetic transition, ring insert
     // and state = observation of its 16 envs (:177-183); a surplus workgroup inserts the new leaves into the tree.
     if (actor_multi_ok(h, n_envs, 1)) { enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0); return; }
+    // (n_step > 1 is k_actor only: dqn_create's capacity >= max_batch check below keeps actor_multi_ok true for one step)
     FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);
     p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
     const EnvArgs e = env_args(h, n_envs, rebuild_top);
@@ -659,6 +675,7 @@ extern "C" int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, fl
     REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch, "n_envs=%d exceeds max_batch=%d", n_envs, h->cfg.max_batch);
     h->p_done = p_done;
     HIP_TRY(hipMemsetAsync(h->env_t, 0, (size_t)n_envs * 4, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(&h->st->hist_steps, 0, sizeof(unsigned long long), (hipStream_t)stream));   // n-step history restarts
     HIP_TRY(hipMemcpyAsync(h->env_obs, obs, (size_t)n_envs * h->cfg.obs_dim * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DQN_OK;
 }

@@ -31,7 +31,8 @@ struct DqnState {
     unsigned int       pad;
     unsigned long long ep_count;       // finished episodes of the device-resident envs (CartPole)
     unsigned long long ep_steps;       // env steps (= return, reward 1 per step) summed over finished episodes
-    unsigned long long tree_ready;     // ring counter up to which the leaves are in the tree: released by the tree
+    unsigned long long hist_steps;     // vector env steps filed in the n-step history since dqn_env_reset
+    unsigned long long tree_ready;     // env step counter up to which the leaves are in the tree: released by the tree
                                        // workgroup of an actor launch, awaited by its sampler workgroups (dqn_actor.hip)
 };
 

@@ -130,6 +130,9 @@ struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic e
     int32_t *env_t;         // per-env step counter
     float term_reward;      // CartPole: reward of the step that terminates the episode (gym: 1; see dqn_env_config)
     int rebuild_top;        // the surplus tree workgroup first rebuilds the dense top of the tree (deferred k_per_top)
+    // n-step returns (dqn_config.n_step > 1; k_actor only): per-env history of the last n_step steps, [n_step][hist_stride]
+    int n_step, hist_stride; float gamma;
+    float *hist_s, *hist_r; int32_t *hist_a, *hist_d;
 };
 
 // ---- CartPole-v1 (classic control; BASELINE.json configs[2]). Euler step of the published cart-pole equations in

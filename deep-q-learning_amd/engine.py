@@ -40,6 +40,7 @@ class EngineConfig:
     precision: str = "f32"
     seed: int = 0
     world_size: int = 1
+    n_step: int = 1                   # n-step returns of the device-resident vector actor (not in the reference)
 
     @property
     def dims(self):
@@ -82,7 +83,7 @@ class Engine:
         c.lr, c.b1, c.b2, c.eps, c.weight_decay = cfg.lr, cfg.b1, cfg.b2, cfg.eps, cfg.weight_decay
         c.gamma, c.per_alpha, c.per_eps, c.per_beta = cfg.gamma, cfg.per_alpha, cfg.per_eps, cfg.per_beta
         c.precision = {"f32": L.PREC_F32, "bf16": L.PREC_BF16}[cfg.precision]
-        c.seed, c.world_size = cfg.seed, cfg.world_size
+        c.seed, c.world_size, c.n_step = cfg.seed, cfg.world_size, cfg.n_step
         h = C.c_void_p()
         L.check(self.lib.dqn_create(C.byref(c), C.byref(h)))
         self.h = h

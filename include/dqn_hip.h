@@ -69,7 +69,11 @@ typedef struct {
     int32_t precision;        /* dqn_precision                                              */
     uint64_t seed;            /* Philox key for the handle's own draws (fused path)         */
     int32_t world_size;       /* gradient is divided by this inside the optimizer           */
-    int32_t reserved;
+    int32_t n_step;           /* n-step returns of the device-resident vector actor (not in the
+                               * reference): 0 / 1 = off; 2..8: every env keeps its last n_step (s, a, r, done) and each
+                               * vector step adds the row (s_u, a_u, R, s_{t+1}, done_n) of the window u = t-n_step+1 .. t,
+                               * R = r_u + gamma*(r_{u+1} + gamma*(...)) cut after the first done; updates bootstrap
+                               * with gamma^n_step. Rows from dqn_replay_add are stored as given. */
 } dqn_config;
 
 const char *dqn_last_error(void);

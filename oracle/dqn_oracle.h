@@ -122,6 +122,9 @@ typedef struct {
     uint64_t seed, ctr;
     /* workspace, sized for max batch */
     int32_t maxB; int32_t *idx, *a; float *isw, *s, *s2, *r, *df, *targets, *delta, *grad; uint8_t *d;
+    /* n-step returns of the vector actor (build spec; not in the reference): n_step <= 1 = off */
+    int32_t n_step, hist_n; uint64_t hist_steps; float gamma_n;
+    float *hist_s, *hist_r; int32_t *hist_a; uint8_t *hist_d;
 } orc_learner;
 int   orc_learner_init(orc_learner *l, orc_dims m, orc_opt opt, float gamma, int32_t maxB,
                        orc_replay *rb, orc_per *per, const float *P0, uint64_t seed);
@@ -130,6 +133,11 @@ float orc_learner_update(orc_learner *l, int32_t B);
 /* q_agent.py:176-183 for n envs: act (epsilon-greedy) -> synthetic transition -> replay.add (+PER leaf) ->
  * state = observation. obs is [n,D] and is advanced in place; *env_ctr is incremented. */
 void  orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon, float p_done, uint64_t *env_ctr);
+/* n-step returns for the vector actor: every env keeps its last n_step (s, a, r, done); from the (n_step)-th step after
+ * this call on, each vector step adds ONE row per env: (s_u, a_u, R, s_{t+1}, done_n) for the window u = t-n_step+1 .. t,
+ * R = r_u + gamma*(r_{u+1} + gamma*(...)) cut after the first done in the window (done_n = 1 then). The update then
+ * bootstraps with gamma^n_step (f32 product gamma*gamma*...). Resets the history. */
+void  orc_learner_set_nstep(orc_learner *l, int32_t n_step, int32_t n_envs);
 
 #ifdef __cplusplus
 }

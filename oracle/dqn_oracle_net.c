@@ -266,7 +266,20 @@ int orc_learner_init(orc_learner *l, orc_dims m, orc_opt opt, float gamma, int32
     return 0;
 }
 
+void orc_learner_set_nstep(orc_learner *l, int32_t n_step, int32_t n_envs) {
+    free(l->hist_s); free(l->hist_a); free(l->hist_r); free(l->hist_d);
+    l->hist_s = NULL; l->hist_a = NULL; l->hist_r = NULL; l->hist_d = NULL;
+    l->n_step = n_step; l->hist_n = n_envs; l->hist_steps = 0; l->gamma_n = l->gamma;
+    if (n_step <= 1) return;
+    for (int32_t i = 1; i < n_step; ++i) l->gamma_n = l->gamma_n * l->gamma;
+    l->hist_s = (float *)calloc((size_t)n_step * n_envs * l->m.D, sizeof(float));
+    l->hist_a = (int32_t *)calloc((size_t)n_step * n_envs, sizeof(int32_t));
+    l->hist_r = (float *)calloc((size_t)n_step * n_envs, sizeof(float));
+    l->hist_d = (uint8_t *)calloc((size_t)n_step * n_envs, 1);
+}
+
 void orc_learner_free(orc_learner *l) {
+    free(l->hist_s); free(l->hist_a); free(l->hist_r); free(l->hist_d);
     free(l->P); free(l->Pt); free(l->mu); free(l->nu); free(l->grad); free(l->idx); free(l->a);
     free(l->isw); free(l->s); free(l->s2); free(l->r); free(l->df); free(l->d); free(l->targets); free(l->delta);
     memset(l, 0, sizeof(*l));
@@ -280,7 +293,7 @@ float orc_learner_update(orc_learner *l, int32_t B) {
     l->ctr += 1;
     orc_replay_gather(l->rb, l->idx, B, l->s, l->a, l->r, l->s2, l->d);
     for (int32_t i = 0; i < B; ++i) l->df[i] = l->d[i] ? 1.0f : 0.0f;   /* preprocessing :84 */
-    orc_q_targets(l->m, l->P, l->Pt, l->s, l->a, l->r, l->s2, l->df, l->gamma, B,
+    orc_q_targets(l->m, l->P, l->Pt, l->s, l->a, l->r, l->s2, l->df, l->n_step > 1 ? l->gamma_n : l->gamma, B,
                   l->targets, NULL, NULL, NULL, NULL, l->delta);
     orc_grads(l->m, l->P, l->s, l->targets, l->per ? l->isw : NULL, B, l->grad, &loss, NULL);
     orc_adam_step(l->opt, l->P, l->grad, l->mu, l->nu, &l->count, &l->b1pow, &l->b2pow,
@@ -325,6 +338,35 @@ void orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon
     uint8_t *d = (uint8_t *)malloc(n);
     orc_act(l->m, l->P, obs, n, epsilon, l->seed, *env_ctr, a);                 /* q_agent.py:176 */
     orc_synth_env(n, D, l->seed, *env_ctr, p_done, next, r, d);                  /* :177 (synthetic) */
+    if (l->n_step > 1) {
+        /* n-step: file this step in the history; once n_step entries exist, add the row of the oldest window */
+        const int32_t ns = l->n_step;
+        const int32_t pos = (int32_t)(l->hist_steps % (uint64_t)ns);
+        memcpy(l->hist_s + (size_t)pos * n * D, obs, sizeof(float) * (size_t)n * D);
+        memcpy(l->hist_a + (size_t)pos * n, a, sizeof(int32_t) * n);
+        memcpy(l->hist_r + (size_t)pos * n, r, sizeof(float) * n);
+        memcpy(l->hist_d + (size_t)pos * n, d, n);
+        if (l->hist_steps + 1 >= (uint64_t)ns) {
+            const int32_t pu = (pos + 1) % ns;                                   /* oldest entry of the window */
+            float *R = (float *)malloc(sizeof(float) * n); uint8_t *dn = (uint8_t *)malloc(n);
+            for (int32_t i = 0; i < n; ++i) {
+                int32_t last = ns - 1;                                           /* window cut after the first done */
+                for (int32_t k = 0; k < ns; ++k) if (l->hist_d[(size_t)((pu + k) % ns) * n + i]) { last = k; break; }
+                float acc = l->hist_r[(size_t)((pu + last) % ns) * n + i];
+                for (int32_t k = last - 1; k >= 0; --k) acc = l->hist_r[(size_t)((pu + k) % ns) * n + i] + l->gamma * acc;
+                R[i] = acc;
+                dn[i] = l->hist_d[(size_t)((pu + last) % ns) * n + i];
+            }
+            orc_replay_add(l->rb, l->hist_s + (size_t)pu * n * D, l->hist_a + (size_t)pu * n, R, next, dn, n, slots);
+            if (l->per) orc_per_add(l->per, slots, n);
+            free(R); free(dn);
+        }
+        l->hist_steps += 1;
+        memcpy(obs, next, sizeof(float) * (size_t)n * D);
+        *env_ctr += 1;
+        free(a); free(slots); free(next); free(r); free(d);
+        return;
+    }
     orc_replay_add(l->rb, obs, a, r, next, d, n, slots);                         /* :182 */
     if (l->per) orc_per_add(l->per, slots, n);
     memcpy(obs, next, sizeof(float) * (size_t)n * D);                            /* :183 */

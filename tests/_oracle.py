@@ -47,7 +47,10 @@ class Learner(C.Structure):
                 ("idx", C.POINTER(C.c_int32)), ("a", C.POINTER(C.c_int32)), ("isw", C.POINTER(C.c_float)),
                 ("s", C.POINTER(C.c_float)), ("s2", C.POINTER(C.c_float)), ("r", C.POINTER(C.c_float)),
                 ("df", C.POINTER(C.c_float)), ("targets", C.POINTER(C.c_float)),
-                ("delta", C.POINTER(C.c_float)), ("grad", C.POINTER(C.c_float)), ("d", C.POINTER(C.c_uint8))]
+                ("delta", C.POINTER(C.c_float)), ("grad", C.POINTER(C.c_float)), ("d", C.POINTER(C.c_uint8)),
+                ("n_step", C.c_int32), ("hist_n", C.c_int32), ("hist_steps", C.c_uint64), ("gamma_n", C.c_float),
+                ("hist_s", C.POINTER(C.c_float)), ("hist_r", C.POINTER(C.c_float)), ("hist_a", C.POINTER(C.c_int32)),
+                ("hist_d", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -224,6 +227,10 @@ class CLearner:
 
     def sync_target(self):
         C.memmove(self.l.Pt, self.l.P, self.n * 4)
+
+    def set_nstep(self, n_step, n_envs):
+        """n-step returns for the vector actor (orc_learner_set_nstep); resets the history"""
+        lib().orc_learner_set_nstep(C.byref(self.l), C.c_int32(n_step), C.c_int32(n_envs))
 
     def actor_step(self, obs, epsilon, p_done, env_ctr):
         """advances obs in place; returns the new env counter"""

@@ -392,6 +392,77 @@ def test_actor_steps_one_launch_bitexact(dq, dims, n, T, L_, per):
     e.close()
 
 
+@pytest.mark.parametrize("n_step,T,per", [(3, 1, True), (3, 4, True), (2, 4, False), (5, 3, True)])
+def test_nstep_actor_bitexact(dq, n_step, T, per):
+    """n-step returns of the vector actor (not in the reference): warm-up, window returns cut at the
+    first done, ring slots, tree and counters after several launches equal the oracle's sequential n-step actor."""
+    import torch
+    dims = CFGS["cfg1"]
+    D = dims[0]
+    L_, n = 12, 37
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=64, seed=77, n_step=n_step)
+    cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
+    P0 = rand_params(dims, 78)
+    e.set_params(P0)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, 64, cr, ct, P0, 77)
+    lrn.set_nstep(n_step, n)
+    obs = np.random.default_rng(79).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.2); e.set_epsilon(0.25)           # p_done 0.2: most windows contain a done
+    ctr = 0
+    with torch.cuda.stream(e.stream):
+        for _ in range(N // (T * n) + 3):                       # wraps the ring
+            for _ in range(T):
+                ctr = lrn.actor_step(obs, 0.25, 0.2, ctr)
+            e.actor_steps(T)
+        e.stream.synchronize()
+    L = dq._lib
+    assert e.replay_size() == (cr.size, cr.rb.counter)
+    got = (e.buffer(L.BUF_STATES).view(N, D), e.buffer(L.BUF_ACTIONS, torch.int32), e.buffer(L.BUF_REWARDS),
+           e.buffer(L.BUF_OBSERVATIONS).view(N, D), e.buffer(L.BUF_DONES, torch.uint8))
+    for x, y in zip(got, cr.arrays()):
+        assert np.array_equal(host(x), y)
+    assert np.array_equal(host(e.buffer(L.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
+    if per:
+        assert np.array_equal(host(e.buffer(L.BUF_TREE)), ct.tree)
+    e.close()
+
+
+def test_nstep_training_loop_matches_oracle(dq):
+    """the captured inner loop with 3-step returns (rows R + gamma^3 bootstrap) vs the oracle stepping the same loop"""
+    import torch
+    dims = CFGS["cfg1"]
+    D = dims[0]
+    L_, n, B = 13, 64, 64
+    N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=91, lr=1e-3, n_step=3)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, 512, 92, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    ct.add(cr.add(s, a, r, s2, d > 0)); e.replay_add(s, a, r, s2, d > 0)
+    P0 = rand_params(dims, 93)
+    e.set_params(P0); e.sync_target()
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 91, beta=0.4)
+    lrn.set_nstep(3, n)
+    obs = np.random.default_rng(94).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
+    ctr = 0
+    for _ in range(6):
+        for _ in range(4):
+            ctr = lrn.actor_step(obs, 0.2, 0.05, ctr)
+        lrn.update(B)
+    with torch.cuda.stream(e.stream):
+        e.train_iters(3, 4, B); e.train_iters(3, 4, B)
+        e.stream.synchronize()
+    assert e.replay_size() == (cr.size, cr.rb.counter) and cr.rb.counter == 512 + (24 - 2) * n
+    assert e.opt_count() == 6
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
+    for x, y in zip((e.buffer(dq._lib.BUF_STATES).view(N, D), e.buffer(dq._lib.BUF_REWARDS)), (cr.arrays()[0], cr.arrays()[2])):
+        assert np.array_equal(host(x), y)
+    assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    e.close()
+
+
 def test_profile_hooks_and_error_paths(dq):
     """dqn_profile_* returns one entry per launch; bad arguments come back as errors, not crashes"""
     import torch
