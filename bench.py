@@ -32,7 +32,7 @@ LOG2N = 20
 B = 1024
 N_ENVS = 256
 TRAIN_FREQ = 4            # Test/lunar_lander.py:30
-ITERS_PER_GRAPH = 10      # inner-loop iterations captured per hipGraph launch (single GPU)
+ITERS_PER_GRAPH = int(os.environ.get("DQN_BENCH_ITERS_PER_GRAPH", "20"))      # inner-loop iterations captured per hipGraph launch (single GPU)
 P_DONE = 0.01
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3
