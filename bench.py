@@ -55,6 +55,8 @@ def algorithmic_cost(name, L, n_params):
         return "hbm", ((4 * D + 5) + 2 * (8 * D + 9) + (8 * L + 4)) * N_ENVS
     if name in ("qnet_fwd_x3", "sample_fwd_x3"):     # three forwards (+ the fused PER sampling of their rows)
         return "mfma", 3 * F * B
+    if name == "sample_fwd_x3_bwd":                  # + TD / Huber gradient / row backward of the same tiles
+        return "mfma", (3 * F + 2 * (1 + A) * H2 + 2 * H1 * H2) * B
     if name in ("act_fwd_policy", "actor_step"):      # forward + policy + env step + ring/tree insert, one launch
         return "mfma", F * N_ENVS
     if name == "actor_steps":         # k_actor: TRAIN_FREQ vector env steps in one launch (+ leaves, + next batch's PER draw)
@@ -71,7 +73,7 @@ def algorithmic_cost(name, L, n_params):
 PMC_KEYS = {   # bench kernel label -> (kernel name in profiles/*_pmc.json, FETCH_SIZE correction)
     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports 1/2 of wide (16 B/lane) coalesced reads; other widths
     # are uncalibrated and taken as reported. The forward kernel appears once per grid size (actor vs 3-pass launch).
-    "actor_steps": ("k_actor", 1.0), "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3": ("k_qnet_fwd:max", 2.0),
+    "actor_steps": ("k_actor", 1.0), "actor_step": ("k_qnet_fwd:min", 2.0), "qnet_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3": ("k_qnet_fwd:max", 2.0), "sample_fwd_x3_bwd": ("k_qnet_fwd:max", 2.0),
     "td_bwd_rows": ("k_bwd_rows", 2.0), "dw_adam_perwrite": ("k_dw", 2.0), "dw_perwrite": ("k_dw", 2.0), "dw_adam": ("k_dw", 2.0), "dw": ("k_dw", 2.0),
     "per_sample": ("k_per_sample", 1.0), "per_top": ("k_per_top", 1.0),
 }
@@ -362,7 +364,7 @@ def main():
                               "frac": ach / peak}
         # dominant KERNEL = largest time share per step. k_qnet_fwd is launched in two shapes (4 actor launches of
         # 256 rows + 1 three-pass launch of 3x1024 rows): its roofline entry aggregates all five launches of a step.
-        groups = {"k_qnet_fwd": [k for k in ("actor_step", "qnet_fwd_x3", "sample_fwd_x3") if k in per_step]}
+        groups = {"k_qnet_fwd": [k for k in ("actor_step", "qnet_fwd_x3", "sample_fwd_x3", "sample_fwd_x3_bwd") if k in per_step]}
         fwd_shapes = " + ".join(f"{per_step[k]['launches_per_step']} x {k}" for k in groups["k_qnet_fwd"])
         for k in per_step:
             if k not in groups["k_qnet_fwd"]:

@@ -80,9 +80,11 @@ struct dqn_handle {
     float *q = nullptr, *nq = nullptr, *nt = nullptr;
     float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
+    int *tile_cnt = nullptr;                                      // per-tile hand-over counters of the fused forward + row backward
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
     float *hist_s = nullptr, *hist_r = nullptr; int32_t *hist_a = nullptr, *hist_d = nullptr;   // n-step history
     int n_step = 1; float gamma_n = 0.0f;
+    bool no_fuse_rows = getenv("DQN_NO_FUSE_ROWS") != nullptr;    // diagnostic: keep k_bwd_rows as its own launch
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
@@ -107,8 +109,9 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
     } else launch_pack(s, h->m, params, pack);
 }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr,
-                  const SampleArgs *smp = nullptr) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp); else launch_qnet_fwd(s, h->m, p, n, B, env, smp);
+                  const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr) {
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp);
+    else launch_qnet_fwd(s, h->m, p, n, B, env, smp, fuse, h->tile_cnt, h->st);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -192,6 +195,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
+    add(&h->tile_cnt, (Bp / 16) * 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
     add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp); add(&h->env_t, Bp * 4);
     if (h->n_step > 1) {
@@ -517,9 +521,6 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
                      make_pass(h, DQN_NET_ONLINE, nullptr, h->nq, nullptr, false),
                      make_pass(h, DQN_NET_TARGET, nullptr, h->nt, nullptr, false) };
     p[0].src = 1; p[1].src = 2; p[2].src = 2;
-    arm(h);
-    L_fwd(h, st, p, 3, B, nullptr, &sm);
-    mark(h, st, "sample_fwd_x3");
     // targets + loss gradient + row backward (q_learning_functions.py:55-60, :35-36, :23)
     BwdArgs g{};
     g.q = h->q; g.nq = h->nq; g.nt = h->nt; g.a = h->ba; g.r = h->br; g.d_u8 = h->bd;
@@ -528,9 +529,17 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
+    // f32, whole grid resident (3 * tiles <= 256 workgroups) and the batch weights final before the launch (drawn by the
+    // actor launch, or uniform replay): the row backward rides in the forward launch (pass-0 workgroups go on with it)
+    const bool fuse_rows = !h->bf16 && 3 * ((B + 15) / 16) <= 256 && (presampled || !h->cfg.use_per) && !h->no_fuse_rows;
     arm(h);
-    L_bwd(h, st, g, B);
-    mark(h, st, "td_bwd_rows");
+    L_fwd(h, st, p, 3, B, nullptr, &sm, fuse_rows ? &g : nullptr);
+    mark(h, st, fuse_rows ? "sample_fwd_x3_bwd" : "sample_fwd_x3");
+    if (!fuse_rows) {
+        arm(h);
+        L_bwd(h, st, g, B);
+        mark(h, st, "td_bwd_rows");
+    }
     PwArgs pw{};
     if (fuse_pw && h->cfg.use_per)
         pw = PwArgs{h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, h->cfg.per_alpha, h->cfg.per_eps};

@@ -78,8 +78,10 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 };
 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
+// fuse != NULL (f32, three passes, 3 * ceil(B/16) <= 256, batch weights final before the launch): the pass-0 workgroups
+// also run the row backward of their tiles (k_bwd_rows' work); tile_cnt = ceil(B/16) zeroed counters
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
-                     const SampleArgs *smp = nullptr);
+                     const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
 // T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip
 bool actor_multi_supported(const NetDims &m, int n_envs, int T);
 void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,

@@ -230,9 +230,17 @@ struct MmaLayer {
 // (online(s), online(s'), target(s') for compute_q_targets :52-54).
 struct FwdPasses { FwdPass p[3]; };
 
-template <int TN1, int TN2>
+// FUSE: the pass-0 workgroup of a tile goes on with the tile's row backward (what k_bwd_rows does as its own launch) once
+// the tile's other two passes have handed over their Q rows: one launch boundary, one prologue and one drain less per
+// update. The hand-over is 2 x 16 x A floats per tile: written with L1-bypassing stores and drained before the writer
+// bumps the tile's counter, read with L1-bypassing loads after the reader has seen the counter (MI355X_MICROARCH.md,
+// inter-workgroup visibility: the sc1 store / sc1 load form). Only for grids that are resident as a whole (3 * tiles <=
+// 256 workgroups, one per CU): a waiting workgroup then never keeps its partners from being scheduled.
+struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; };
+
+template <int TN1, int TN2, bool FUSE>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
+k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp, FuseBwd fb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     ACTOR_PROLOGUE(lds)
     const FwdPass ps = passes.p[blockIdx.y];
@@ -266,6 +274,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
     int pre_leaf = 0;
     if (presampled && tid < 16) pre_leaf = smp.idx[row0 + tid < B ? row0 + tid : B - 1];
     MmaLayer<TN1, 2, true> L1; MmaLayer<TN2, 16, false> L2; MmaLayer<1, 16, false> LH;
+    MmaLayer<TN2, 1, false> LA; MmaLayer<TN1, 16, false> LB;         // row backward (FUSE, pass 0)
     L1.start(ps.pack + m.p_w1, m.KQ1, m.H1 / 16, wave, lane);
     float bias1[TN1], bias2[TN2], biash = 0.0f;
 #pragma unroll
@@ -277,12 +286,16 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         if (c == 0) biash = ps.params[m.o_bv];
         else if (c <= m.A) biash = ps.params[m.o_ba + c - 1];
     }
+    int row_a = 0; float row_r = 0.0f; int row_d = 0;               // a, r, d of this thread's row (FUSE, pass 0)
     if (presampled) {
         // rows of this tile: requested ahead of the layer-2 weights (in-order returns); pass 0 publishes a, r, d
         if (tid < 16) {
             lidx[tid] = pre_leaf;
             const int k = row0 + tid;
-            if (blockIdx.y == 0 && k < B) { smp.a[k] = smp.actions[pre_leaf]; smp.r[k] = smp.rewards[pre_leaf]; smp.d[k] = smp.dones[pre_leaf]; }
+            if (blockIdx.y == 0 && k < B) {
+                row_a = smp.actions[pre_leaf]; row_r = smp.rewards[pre_leaf]; row_d = smp.dones[pre_leaf];
+                smp.a[k] = row_a; smp.r[k] = row_r; smp.d[k] = (uint8_t)row_d;
+            }
         }
         LDS_BARRIER();
 #pragma unroll
@@ -304,6 +317,12 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) xv[u] = xload(tid + 256 * u);
+        if constexpr (FUSE) {
+            if (blockIdx.y == 0 && tid < 16 && row0 + tid < B) {
+                const int leaf = lidx[tid];
+                row_a = smp.actions[leaf]; row_r = smp.rewards[leaf]; row_d = smp.dones[leaf];
+            }
+        }
     }
 
     // stage the 16 input rows (zero-padded) in A-operand order
@@ -325,6 +344,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
     LDS_BARRIER();
     STAMP(0, 1);
 
+    unsigned m1bits = 0u, m2bits = 0u;                               // ReLU gates of this lane's accumulator elements (FUSE)
     // layer 1: h1 = relu(x @ w1 + b1)                                      dddqn.py:25-26
     {
         f32x4 acc[TN1];
@@ -340,6 +360,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
                     const int rl = 4 * (lane >> 4) + r;
                     float v = acc[t][r] + bias;
                     v = v > 0.0f ? v : 0.0f;
+                    if constexpr (FUSE) m1bits |= (v > 0.0f ? 1u : 0u) << (4 * t + r);
                     l1[rl * s1 + 16 * ct + perm16(c)] = v;
                     if (ps.ph1) ps.ph1[pfrag(KQb, tile, ct, r, lane)] = v;
                 }
@@ -366,6 +387,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
                     const int rl = 4 * (lane >> 4) + r;
                     float v = acc[t][r] + bias;
                     v = v > 0.0f ? v : 0.0f;
+                    if constexpr (FUSE) m2bits |= (v > 0.0f ? 1u : 0u) << (4 * t + r);
                     l2[rl * s2 + 16 * ct + perm16(c)] = v;
                     if (ps.ph2) ps.ph2[pfrag(KQb, tile, ct, r, lane)] = v;
                     if (ps.feat && row0 + rl < B) ps.feat[(long long)(row0 + rl) * m.H2 + col] = v;   // :32-33
@@ -384,17 +406,39 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[0][r] + biash;
     }
+    if constexpr (FUSE) {
+        // the row backward's weights ([wv|wa]^T, then all of W2^T into the registers layer 2 has freed): waves 1..3 request
+        // them while they would idle behind the heads, wave 0 right after its heads; they land behind the TD rows
+        if (blockIdx.y == 0) {
+            LA.start(fb.g.pack + m.p_wht, 1, m.H2 / 16, wave, lane);
+            LB.init(fb.g.pack + m.p_w2t, m.H2 / 16, m.H1 / 16, wave, lane);
+            LB.template load_range<0, 16>();
+        }
+    }
     LDS_BARRIER();
     STAMP(0, 5);
 
     // Q = val + adv - mean(adv)                                            dddqn.py:31
+    float qrow[16];
     if (tid < 16 && row0 + tid < B) {
         const float *hr = lh + tid * 16;
-        float sum = 0.0f, qrow[16];
-        for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
+        float sum = 0.0f;
+        if constexpr (FUSE) {                                        // statically indexed (the row backward keeps qrow in registers)
+#pragma unroll
+            for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+        } else {
+            for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
+        }
         const float mean = __fdiv_rn(sum, (float)m.A);
-        for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
-        if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int a = 0; a < 15; ++a) qrow[a] = a < m.A ? (hr[0] + hr[1 + a]) - mean : 0.0f;
+        } else {
+            for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
+        }
+        if (FUSE && blockIdx.y != 0) {
+            for (int a = 0; a < m.A; ++a) __hip_atomic_store(&ps.q[(long long)(row0 + tid) * m.A + a], qrow[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
         if (ps.act_out) {
             const float eps = ps.act_state ? ps.act_state->epsilon : ps.act_eps;
             const unsigned long long ctr = ps.act_state ? ps.act_state->env_ctr : ps.act_ctr;
@@ -410,12 +454,139 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp) {
         actor_commit(env, env_c0, env_ec, gridDim.x);
     }
     STAMP(0, 6);
+    if constexpr (FUSE) {
+        if (blockIdx.y != 0) {
+            // passes 1, 2: the Q rows above were L1-bypassing stores of wave 0; drain them, then count this pass in
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tid == 0) atomicAdd(&fb.tile_cnt[tile], 1);
+            }
+            return;
+        }
+        // ---- pass 0: TD target / Huber gradient / row backward of this tile (the body of k_bwd_rows)
+        const BwdArgs &g = fb.g;
+        const int A = m.A;
+        const int s3 = 16 + 4;
+        float *l3 = lx;                                              // [16][20] (x is dead), 16 * sx >= 16 * 20
+        float *lz2 = lh + 256 + 32 + 528, *lrow = lz2 + 16 * s2;      // dz2 [16][s2], per-row loss [16]
+        const int irow = row0 + tid;
+        const bool rowt = tid < 16 && irow < B;
+        float wi = 1.0f, wmax = 1.0f;
+        if (rowt && g.w_raw) { wi = g.w_raw[irow]; wmax = fb.st->wmax; }
+        for (int t = tid; t < 16 * s3; t += 256) l3[t] = 0.0f;
+        if (tid == 0) {
+            // bounded wait (~0.3 s): the launcher only fuses grids that are resident as a whole, so the partners are
+            // running; should that ever not hold, the kernel still ends and the loss turns NaN instead of the GPU hanging
+            int spins = 0;
+            while (__hip_atomic_load(&fb.tile_cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2 && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(2);
+            if (spins >= (1 << 22)) g.loss_part[tile] = __int_as_float(0x7fc00000);
+            __hip_atomic_store(&fb.tile_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+        }
+        LDS_BARRIER();                                               // partners' rows are in L2; l3 is zeroed
+        STAMP(0, 7);
+        if (tid < 16) {
+            float rowloss = 0.0f;
+            if (rowt) {
+                // q_learning_functions.py:55-60 + :35-36 for one row, written with statically indexed registers
+                // (unrolled to the 15-action maximum, predicated on k < A): same operations in the same order as
+                // td_row() / k_bwd_rows
+                float nqr[15], ntr[15];
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) {
+                    nqr[k2] = k2 < A ? __hip_atomic_load(&g.nq[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                    ntr[k2] = k2 < A ? __hip_atomic_load(&g.nt[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                }
+                float w = 1.0f;
+                if (g.w_raw) { w = __fdiv_rn(wi, wmax); if (g.isw_out) g.isw_out[irow] = w; }
+                const float invB = __fdiv_rn(1.0f, (float)B);
+                float best = nqr[0], nt_star = ntr[0], q_a = qrow[0];   // :55 argmax, first max wins; q[action]
+#pragma unroll
+                for (int k2 = 1; k2 < 15; ++k2) {
+                    if (k2 < A && nqr[k2] > best) { best = nqr[k2]; nt_star = ntr[k2]; }
+                    if (k2 == row_a) q_a = qrow[k2];
+                }
+                const float di = row_d ? 1.0f : 0.0f;                   // preprocessing :84
+                const float t1 = g.gamma * nt_star;                      // :58, quirk Q3: (1-d) covers -q too
+                const float t2 = t1 - q_a;
+                const float t3 = (1.0f - di) * t2;
+                const float delta = row_r + t3;
+                if (g.td) g.td[irow] = delta;
+                if (g.td_abs) g.td_abs[irow] = fabsf(delta);
+                float gk[15], gsum = 0.0f;
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) {
+                    gk[k2] = 0.0f;
+                    if (k2 < A) {
+                        const float trk = qrow[k2] + delta * (k2 == row_a ? 1.0f : 0.0f);   // :59, quirk Q4
+                        const float e = qrow[k2] - trk;                 // pred - target, pred == q   (:35)
+                        rowloss = rowloss + huber(e);                   // :36
+                        const float c = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+                        gk[k2] = (w * c) * invB;                        // dL/dpred
+                        gsum = gsum + gk[k2];
+                        if (g.dq) g.dq[(long long)irow * A + k2] = gk[k2];
+                        if (g.targets_out) g.targets_out[(long long)irow * A + k2] = trk;
+                    }
+                }
+                if (g.w_raw) rowloss = w * rowloss;
+                const float gmean = __fdiv_rn(gsum, (float)A);           // dueling backward: dv = sum_a g_a ; dadv_j = g_j - mean
+                l3[tid * s3 + perm16(0)] = gsum;
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) if (k2 < A) l3[tid * s3 + perm16(1 + k2)] = gk[k2] - gmean;
+            }
+            lrow[tid] = rowloss;
+        }
+        LDS_BARRIER();
+        STAMP(0, 8);
+        if (tid == 0) {
+            float sl = 0.0f;
+            for (int k = 0; k < 16; ++k) sl = sl + lrow[k];
+            g.loss_part[tile] = sl + (g.loss_part[tile] != g.loss_part[tile] ? g.loss_part[tile] : 0.0f);   // keeps a wait-timeout NaN
+        }
+        {   // stash dz3 (packed, K = batch, C = 16)
+            const int rl = tid >> 4, c = tid & 15;
+            g.pdz3[pidx(KQb, row0 + rl, c)] = l3[rl * s3 + perm16(c)];
+        }
+        {   // dz2 = (dz3 . WH^T) * (h2 > 0)
+            f32x4 acc[TN2];
+            LA.finish(l3, s3, lane, acc);
+#pragma unroll
+            for (int t = 0; t < TN2; ++t) {
+                const int ct = wave + 4 * t;
+                if (ct < m.H2 / 16) {
+                    const int c = lane & 15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = 4 * (lane >> 4) + r;
+                        const float v = ((m2bits >> (4 * t + r)) & 1u) ? acc[t][r] : 0.0f;
+                        lz2[rl * s2 + 16 * ct + perm16(c)] = v;
+                        g.pdz2[pfrag(KQb, tile, ct, r, lane)] = v;
+                    }
+                }
+            }
+        }
+        LDS_BARRIER();
+        STAMP(0, 9);
+        {   // dz1 = (dz2 . W2^T) * (h1 > 0)
+            f32x4 acc[TN1];
+            LB.finish(lz2, s2, lane, acc, true);
+#pragma unroll
+            for (int t = 0; t < TN1; ++t) {
+                const int ct = wave + 4 * t;
+                if (ct < m.H1 / 16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g.pdz1[pfrag(KQb, tile, ct, r, lane)] = ((m1bits >> (4 * t + r)) & 1u) ? acc[t][r] : 0.0f;
+                }
+            }
+        }
+        STAMP(0, 10);
+    }
 }
 
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
 
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
-                     const SampleArgs *smp) {
+                     const SampleArgs *smp, const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
     FwdPasses ps{};
     for (int i = 0; i < npass; ++i) ps.p[i] = passes[i];
     const EnvArgs ea = env ? *env : EnvArgs{};
@@ -426,7 +597,16 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * ((size_t)1 << (ea.L < PW_TOP ? ea.L : PW_TOP)); if (lds < need) lds = need; }
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2>), grid, block, lds, s, m, ps, B, ea, sa); return; }
+    if (fuse) {
+        FuseBwd fb{*fuse, tile_cnt, st};
+        lds += sizeof(float) * (16 * (m.H2 + 4) + 16);
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, true>), grid, block, lds, s, m, ps, B, ea, sa, fb); return; }
+        FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
+        FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
+#undef FWD_CASE
+    }
+    const FuseBwd fb{};
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, false>), grid, block, lds, s, m, ps, B, ea, sa, fb); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE

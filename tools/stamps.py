@@ -15,7 +15,8 @@ os.environ.setdefault("DQN_HIP_LIB", os.path.join(ROOT, "deep-q-learning_amd", "
 import bench  # noqa: E402
 import deep_q_learning_amd as dq  # noqa: E402
 
-NAMES = {0: ("k_qnet_fwd", ["start", "x staged", "L1 done", "L2 mfma done", "L2 epilogue", "heads done", "end"]),
+NAMES = {0: ("k_qnet_fwd (+ fused row backward)", ["start", "x staged", "L1 done", "L2 mfma done", "L2 epilogue", "heads done", "forward end",
+                                                    "partners' Q rows in", "TD rows done", "dz2 done", "dz1 done"]),
          1: ("k_env_step", ["start", "synth+ring stores", "leaves set", "levels done", "post barrier"]),
          4: ("k_per_write_sorted", ["start", "ownership found", "leaf + sib loads", "levels done", "end"]),
          5: ("k_bwd_rows", ["start", "prefetch issued + wmax", "td rows done", "dz2 done", "end"]),
