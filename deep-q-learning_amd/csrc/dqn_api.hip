@@ -110,7 +110,7 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
 }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr,
                   const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp);
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp, fuse, h->tile_cnt, h->st);
     else launch_qnet_fwd(s, h->m, p, n, B, env, smp, fuse, h->tile_cnt, h->st);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
@@ -529,9 +529,10 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
     g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
-    // f32, whole grid resident (3 * tiles <= 256 workgroups) and the batch weights final before the launch (drawn by the
+    // whole grid resident (3 * tiles <= 256 workgroups) and the batch weights final before the launch (drawn by the
     // actor launch, or uniform replay): the row backward rides in the forward launch (pass-0 workgroups go on with it)
-    const bool fuse_rows = !h->bf16 && 3 * ((B + 15) / 16) <= 256 && (presampled || !h->cfg.use_per) && !h->no_fuse_rows;
+    const int grid_tiles = h->bf16 ? 2 * ((B + 31) / 32) : (B + 15) / 16;
+    const bool fuse_rows = 3 * grid_tiles <= 256 && (presampled || !h->cfg.use_per) && !h->no_fuse_rows;
     arm(h);
     L_fwd(h, st, p, 3, B, nullptr, &sm, fuse_rows ? &g : nullptr);
     mark(h, st, fuse_rows ? "sample_fwd_x3_bwd" : "sample_fwd_x3");

@@ -69,6 +69,8 @@ struct BwdArgs {
     float *loss_part;                  // [ceil(B/16)]
 };
 
+struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; };   // row backward fused into the forward launch (k_qnet_fwd<.., FUSE>)
+
 struct PwArgs {             // sorted PER write-back run by surplus workgroups of k_dw when tree != NULL
     float *tree; long long N; int L; const int32_t *idx; const float *td_abs; int B; float alpha, eps;
 };
@@ -133,7 +135,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
-                          const SampleArgs *smp = nullptr);
+                          const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

@@ -236,7 +236,6 @@ struct FwdPasses { FwdPass p[3]; };
 // bumps the tile's counter, read with L1-bypassing loads after the reader has seen the counter (MI355X_MICROARCH.md,
 // inter-workgroup visibility: the sc1 store / sc1 load form). Only for grids that are resident as a whole (3 * tiles <=
 // 256 workgroups, one per CU): a waiting workgroup then never keeps its partners from being scheduled.
-struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; };
 
 template <int TN1, int TN2, bool FUSE>
 __global__ void __launch_bounds__(256)

@@ -150,9 +150,11 @@ static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct
 // ------------------------------------------------------------------------------ forward
 struct FwdPasses16 { FwdPass p[3]; };
 
-template <int TN1, int TN2>
+// FUSE: as k_qnet_fwd<.., true> (dqn_net.hip) -- the pass-0 workgroup of a tile goes on with the tile's row backward
+// once the other two passes have handed over their Q rows (L1-bypassing stores, drained, then the tile's counter)
+template <int TN1, int TN2, bool FUSE>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, SampleArgs smp) {
+k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, SampleArgs smp, FuseBwd fb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ACTOR_PROLOGUE(smem)
     const FwdPass ps = passes.p[blockIdx.y];
@@ -196,11 +198,16 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
         if (c == 0) biash = ps.params[m.o_bv];
         else if (c <= m.A) biash = ps.params[m.o_ba + c - 1];
     }
+    int row_a = 0; float row_r = 0.0f; int row_d = 0;               // a, r, d of this thread's row (FUSE, pass 0)
+    unsigned m1bits = 0u, m2bits = 0u;                               // ReLU gates of this lane's accumulator elements (FUSE)
     if (presampled) {
         if (tid < 16) {
             lidx[tid] = pre_leaf;
             const int k = row0 + tid;
-            if (blockIdx.y == 0 && k < B) { smp.a[k] = smp.actions[pre_leaf]; smp.r[k] = smp.rewards[pre_leaf]; smp.d[k] = smp.dones[pre_leaf]; }
+            if (blockIdx.y == 0 && k < B) {
+                row_a = smp.actions[pre_leaf]; row_r = smp.rewards[pre_leaf]; row_d = smp.dones[pre_leaf];
+                smp.a[k] = row_a; smp.r[k] = row_r; smp.d[k] = (uint8_t)row_d;
+            }
         }
         LDS_BARRIER();
 #pragma unroll
@@ -218,6 +225,12 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) xv[u] = xload(tid + 256 * u);
+        if constexpr (FUSE) {
+            if (blockIdx.y == 0 && tid < 16 && row0 + tid < B) {
+                const int leaf = lidx[tid];
+                row_a = smp.actions[leaf]; row_r = smp.rewards[leaf]; row_d = smp.dones[leaf];
+            }
+        }
     }
 
     // zero the k-padding columns of the hidden activations (hidden % 32 == 16 only)
@@ -255,6 +268,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
                     float v = acc[t][r] + bias1[t];
                     v = v > 0.0f ? v : 0.0f;
                     const __bf16 b = (__bf16)v;
+                    if constexpr (FUSE) m1bits |= ((float)b > 0.0f ? 1u : 0u) << (4 * t + r);
                     l1[rl * s1 + col] = b;
                     if (ph1) ph1[pidx16(KQb, row0 + rl, col)] = b;
                 }
@@ -277,6 +291,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
                     float v = acc[t][r] + bias2[t];
                     v = v > 0.0f ? v : 0.0f;
                     const __bf16 b = (__bf16)v;
+                    if constexpr (FUSE) m2bits |= ((float)b > 0.0f ? 1u : 0u) << (4 * t + r);
                     l2[rl * s2 + col] = b;
                     if (ph2) ph2[pidx16(KQb, row0 + rl, col)] = b;
                     if (ps.feat && row0 + rl < B) ps.feat[(long long)(row0 + rl) * m.H2 + col] = (float)b;
@@ -293,15 +308,35 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
 #pragma unroll
         for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[0][r] + biash;
     }
+    MmaLayer16<TN2, 1> LA; MmaLayer16<TN1, 8> LB;                             // row backward (FUSE, pass 0)
+    if constexpr (FUSE) {
+        if (blockIdx.y == 0) {
+            LA.start(reinterpret_cast<const __bf16 *>(fb.g.pack) + d.p_wht, 1, m.H2 / 16, wave, lane);
+            LB.start(reinterpret_cast<const __bf16 *>(fb.g.pack) + d.p_w2t, d.KQH, m.H1 / 16, wave, lane);
+        }
+    }
     LDS_BARRIER();
 
+    float qrow[16];
     if (tid < 16 && row0 + tid < B) {                                       // dddqn.py:31 (+ policy)
         const float *hr = lh + tid * 16;
-        float sum = 0.0f, qrow[16];
-        for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
+        float sum = 0.0f;
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+        } else {
+            for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
+        }
         const float mean = __fdiv_rn(sum, (float)m.A);
-        for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
-        if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int a = 0; a < 15; ++a) qrow[a] = a < m.A ? (hr[0] + hr[1 + a]) - mean : 0.0f;
+        } else {
+            for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
+        }
+        if (FUSE && blockIdx.y != 0) {
+            for (int a = 0; a < m.A; ++a) __hip_atomic_store(&ps.q[(long long)(row0 + tid) * m.A + a], qrow[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
         if (ps.act_out) {
             const float eps = ps.act_state ? ps.act_state->epsilon : ps.act_eps;
             const unsigned long long ctr = ps.act_state ? ps.act_state->env_ctr : ps.act_ctr;
@@ -316,13 +351,134 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
         env_rows(tid, 256, row0, cnt, env_c0, env_ec, env, m.D, reinterpret_cast<const int32_t *>(lh + 256), row0);
         actor_commit(env, env_c0, env_ec, gridDim.x);
     }
+    if constexpr (FUSE) {
+        if (blockIdx.y != 0) {
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the Q rows above have left this CU
+                if (tid == 0) atomicAdd(&fb.tile_cnt[tile], 1);
+            }
+            return;
+        }
+        // ---- pass 0: TD target / Huber gradient / row backward of this tile (the body of k_bwd_rows16)
+        const BwdArgs &g = fb.g;
+        __bf16 *pdz1 = reinterpret_cast<__bf16 *>(g.pdz1), *pdz2 = reinterpret_cast<__bf16 *>(g.pdz2), *pdz3 = reinterpret_cast<__bf16 *>(g.pdz3);
+        const int A = m.A;
+        const int s3 = 32 + 8;
+        __bf16 *l3 = lx;                                             // [16][40] (x is dead; 16 * sx >= 16 * 40)
+        __bf16 *lz2 = reinterpret_cast<__bf16 *>(lh + 256 + 32 + 528);   // dz2 [16][s2]
+        float *lrow = reinterpret_cast<float *>(lz2 + 16 * s2);
+        const int irow = row0 + tid;
+        const bool rowt = tid < 16 && irow < B;
+        float wi = 1.0f, wmax = 1.0f;
+        if (rowt && g.w_raw) { wi = g.w_raw[irow]; wmax = fb.st->wmax; }
+        for (int t = tid; t < 16 * s3; t += 256) l3[t] = (__bf16)0.0f;
+        for (int t = tid; t < 16 * (KH - m.H2); t += 256) lz2[(t / (KH - m.H2)) * s2 + m.H2 + t % (KH - m.H2)] = (__bf16)0.0f;
+        if (tid == 0) {
+            int spins = 0;                                           // bounded wait: see k_qnet_fwd
+            while (__hip_atomic_load(&fb.tile_cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2 && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(2);
+            if (spins >= (1 << 22) && tile < (B + 15) / 16) g.loss_part[tile] = __int_as_float(0x7fc00000);
+            __hip_atomic_store(&fb.tile_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        LDS_BARRIER();
+        if (tid < 16) {
+            float rowloss = 0.0f;
+            if (rowt) {
+                float nqr[15], ntr[15];
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) {
+                    nqr[k2] = k2 < A ? __hip_atomic_load(&g.nq[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                    ntr[k2] = k2 < A ? __hip_atomic_load(&g.nt[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                }
+                float w = 1.0f;
+                if (g.w_raw) { w = __fdiv_rn(wi, wmax); if (g.isw_out) g.isw_out[irow] = w; }
+                const float invB = __fdiv_rn(1.0f, (float)B);
+                float best = nqr[0], nt_star = ntr[0], q_a = qrow[0];   // q_learning_functions.py:55 argmax, first max wins
+#pragma unroll
+                for (int k2 = 1; k2 < 15; ++k2) {
+                    if (k2 < A && nqr[k2] > best) { best = nqr[k2]; nt_star = ntr[k2]; }
+                    if (k2 == row_a) q_a = qrow[k2];
+                }
+                const float di = row_d ? 1.0f : 0.0f;
+                const float t1 = g.gamma * nt_star;                      // :58 (quirk Q3)
+                const float t2 = t1 - q_a;
+                const float t3 = (1.0f - di) * t2;
+                const float delta = row_r + t3;
+                if (g.td) g.td[irow] = delta;
+                if (g.td_abs) g.td_abs[irow] = fabsf(delta);
+                float gk[15], gsum = 0.0f;
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) {
+                    gk[k2] = 0.0f;
+                    if (k2 < A) {
+                        const float trk = qrow[k2] + delta * (k2 == row_a ? 1.0f : 0.0f);   // :59 (quirk Q4)
+                        const float e = qrow[k2] - trk;
+                        rowloss = rowloss + huber(e);
+                        const float c = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+                        gk[k2] = (w * c) * invB;
+                        gsum = gsum + gk[k2];
+                        if (g.dq) g.dq[(long long)irow * A + k2] = gk[k2];
+                        if (g.targets_out) g.targets_out[(long long)irow * A + k2] = trk;
+                    }
+                }
+                if (g.w_raw) rowloss = w * rowloss;
+                const float gmean = __fdiv_rn(gsum, (float)A);
+                l3[tid * s3 + 0] = (__bf16)gsum;
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) if (k2 < A) l3[tid * s3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
+            }
+            lrow[tid] = rowloss;
+        }
+        LDS_BARRIER();
+        if (tid == 0 && tile < (B + 15) / 16) {
+            float sl = 0.0f;
+            for (int k = 0; k < 16; ++k) sl = sl + lrow[k];
+            g.loss_part[tile] = sl + (g.loss_part[tile] != g.loss_part[tile] ? g.loss_part[tile] : 0.0f);
+        }
+        pdz3[pidx16(KQb, row0 + (tid >> 4), tid & 15)] = l3[(tid >> 4) * s3 + (tid & 15)];
+        {   // dz2 = (dz3 . WH^T) * (h2 > 0)
+            f32x4 acc[TN2];
+            LA.finish(l3, s3, lane, acc);
+#pragma unroll
+            for (int t = 0; t < TN2; ++t) {
+                const int ct = wave + 4 * t;
+                if (ct < m.H2 / 16) {
+                    const int c = lane & 15, col = 16 * ct + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = 4 * (lane >> 4) + r;
+                        const __bf16 b = (__bf16)(((m2bits >> (4 * t + r)) & 1u) ? acc[t][r] : 0.0f);
+                        lz2[rl * s2 + col] = b;
+                        pdz2[pidx16(KQb, row0 + rl, col)] = b;
+                    }
+                }
+            }
+        }
+        LDS_BARRIER();
+        {   // dz1 = (dz2 . W2^T) * (h1 > 0)
+            f32x4 acc[TN1];
+            LB.finish(lz2, s2, lane, acc);
+#pragma unroll
+            for (int t = 0; t < TN1; ++t) {
+                const int ct = wave + 4 * t;
+                if (ct < m.H1 / 16) {
+                    const int c = lane & 15, col = 16 * ct + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = 4 * (lane >> 4) + r;
+                        pdz1[pidx16(KQb, row0 + rl, col)] = (__bf16)(((m1bits >> (4 * t + r)) & 1u) ? acc[t][r] : 0.0f);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // tiles are launched in pairs so that every 32-row k-block of the batch-major stashes is fully written
 static inline int tiles16(int B) { return 2 * ((B + 31) / 32); }
 
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
-                          const SampleArgs *smp) {
+                          const SampleArgs *smp, const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
     FwdPasses16 ps{};
     bool stash = false;
     for (int i = 0; i < npass; ++i) { ps.p[i] = passes[i]; stash |= passes[i].px != nullptr; }
@@ -335,7 +491,16 @@ void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
     if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * ((size_t)1 << (ea.L < PW_TOP ? ea.L : PW_TOP)); if (lds < need) lds = need; }
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2>), grid, block, lds, s, m, d, ps, B, ea, sa); return; }
+    if (fuse) {
+        const FuseBwd fb{*fuse, tile_cnt, st};
+        lds += 2 * 16 * (d.KQH * 32 + 8) + 4 * 16;
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, true>), grid, block, lds, s, m, d, ps, B, ea, sa, fb); return; }
+        FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
+        FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
+#undef FWD_CASE
+    }
+    const FuseBwd fb{};
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, false>), grid, block, lds, s, m, d, ps, B, ea, sa, fb); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE

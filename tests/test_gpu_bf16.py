@@ -132,3 +132,35 @@ def test_bf16_actor_loop_runs(dq):
     acts = host(e.buffer(dq._lib.BUF_ENV_ACTIONS, torch.int32))[:256]
     assert acts.min() >= 0 and acts.max() < 4
     e.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_row_backward_equals_separate_launch(dq, precision, monkeypatch):
+    """the row backward riding in the forward launch (pass-0 workgroups continue after the partners' Q-row hand-over)
+    is the same arithmetic as k_bwd_rows / k_bwd_rows16 in its own launch: identical parameters, tree and loss after a
+    captured loop, bit for bit, in both precision modes"""
+    import torch
+    dims = CFGS["cfg2"]
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("DQN_NO_FUSE_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("DQN_NO_FUSE_ROWS", "1")                  # read when the handle is created
+        e = dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=1 << 12,
+                                      use_per=True, max_batch=1024, seed=3, precision=precision))
+        e.set_params(rand_params(dims, 10)); e.sync_target()
+        rng = np.random.default_rng(11)
+        e.replay_add(rng.standard_normal((2048, 8)), rng.integers(0, 4, 2048), rng.standard_normal(2048),
+                     rng.standard_normal((2048, 8)), rng.random(2048) < 0.05)
+        e.env_reset(rng.standard_normal((256, 8)).astype(np.float32), 0.01); e.set_epsilon(0.15)
+        with torch.cuda.stream(e.stream):
+            for _ in range(3):
+                e.train_iters(4, 4, 1024)
+            e.stream.synchronize()
+        out[fused] = (e.get_params(host=True), host(e.buffer(dq._lib.BUF_TREE)).copy(), float(e.last_loss().item()))
+        e.close()
+    assert np.array_equal(out[True][0], out[False][0])
+    assert np.array_equal(out[True][1], out[False][1])
+    assert out[True][2] == out[False][2] and np.isfinite(out[True][2])
+
