@@ -96,6 +96,9 @@ def pmc_traffic(label):
     recs = json.load(open(files[-1]))
     name, _, pick = key.partition(":")
     cands = [k for k in recs if k.split("<")[0].split("/")[0] == name]
+    if name == "k_qnet_fwd":                     # the forward launch with / without the fused row backward (template flag)
+        want = "true>" if label.endswith("_bwd") else "false>"
+        cands = [k for k in cands if want in k or ("true>" not in k and "false>" not in k)]
     if not cands:
         return None
     if pick:                                     # several grid sizes of one kernel: smallest / largest grid

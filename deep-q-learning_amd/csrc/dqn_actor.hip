@@ -140,7 +140,8 @@ __device__ __forceinline__ void nstep_row(const EnvArgs &e, int ns, int hpos, in
 // KB = 16-row k-blocks of the register-resident W2 slab: hidden1 <= 16*KB (columns / rows past hidden1 are zeros, and
 // x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
 // KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
-template <int KB, int KB2>
+// NSTEP: dqn_config.n_step > 1 (compiled apart: the n-step bookkeeping costs scalar registers in the step loop)
+template <int KB, int KB2, bool NSTEP>
 __global__ void __launch_bounds__(256)
 k_actor(NetDims m, ActorArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -149,8 +150,8 @@ k_actor(NetDims m, ActorArgs g) {
     const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
     // n-step returns: a vector step adds rows only once n_step steps are on file, i.e. not during the first `warm` steps
     // after dqn_env_reset (n_step == 1: warm = 0, every step adds its n rows)
-    const unsigned long long hs0 = e.n_step > 1 ? e.st->hist_steps : 0ull;
-    const int warm = (e.n_step > 1 && hs0 + 1ull < (unsigned long long)e.n_step) ? (int)((unsigned long long)e.n_step - 1ull - hs0) : 0;
+    const unsigned long long hs0 = NSTEP ? e.st->hist_steps : 0ull;
+    const int warm = (NSTEP && hs0 + 1ull < (unsigned long long)e.n_step) ? (int)((unsigned long long)e.n_step - 1ull - hs0) : 0;
     const int n_emit = g.T > warm ? g.T - warm : 0;
     const unsigned long long nT = (unsigned long long)n_emit * (unsigned long long)e.n, c1 = c0 + nT;
     const unsigned long long ticket_val = ec + (unsigned long long)g.T;   // flag value of THIS launch (the env step counter only grows)
@@ -301,6 +302,7 @@ k_actor(NetDims m, ActorArgs g) {
         // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
         const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
         bool w2_landed = false;
+        const int hpos0 = NSTEP ? (int)(hs0 % (unsigned long long)e.n_step) : 0;   // one 64-bit modulo per launch, not per step
 
         for (int tile = wg; tile < g.tiles; tile += g.G) {
             const int i0 = 4 * tile;
@@ -317,11 +319,13 @@ k_actor(NetDims m, ActorArgs g) {
             for (int t = 0; t < g.T; ++t) {
                 const bool last = t == g.T - 1;
                 const unsigned long long ect = ec + (unsigned long long)t;
-                const bool emit = t >= warm;                                    // (n-step warm-up: the step is only filed)
+                const bool emit = !NSTEP || t >= warm;                          // (n-step warm-up: the step is only filed)
                 const long long at = a0 + (long long)(emit ? t - warm : 0) * e.n + i0;   // slot of the tile's first env, before the wrap
-                const int ns = e.n_step;
-                const int hpos = ns > 1 ? (int)((hs0 + (unsigned long long)t) % (unsigned long long)ns) : 0;   // history slot of this step
-                const int hold = ns > 1 ? (hpos + 1) % ns : 0;                                                 // oldest step of the window
+                const int ns = NSTEP ? e.n_step : 1;
+                int hpos = 0, hold = 0;                                         // history slot of this step / of the oldest step of the window
+                if constexpr (NSTEP) { hpos = hpos0 + t; hpos -= hpos >= ns ? ns : 0; hpos -= hpos >= ns ? ns : 0;   // (hpos0 < ns, t < 64: loop below)
+                              while (hpos >= ns) hpos -= ns;
+                              hold = hpos + 1 == ns ? 0 : hpos + 1; }
                 const int flagv = (tile - wg) / g.G * g.T + t + 1;              // value the draw flags take in this step
                 // The slabs live in registers for the whole launch: the empty asm makes their values opaque here, so
                 // the compiler can neither re-request them from memory inside the step loop nor forget them.
@@ -458,7 +462,7 @@ k_actor(NetDims m, ActorArgs g) {
                             const bool done = term || tt >= e.max_steps;             // q_agent.py:179-180
                             float rew = term ? e.term_reward : 1.0f;
                             int a_row = act, d_row = done ? 1 : 0;
-                            if (ns > 1) {
+                            if constexpr (NSTEP) {
                                 for (int j = 0; j < 4; ++j) {
                                     e.hist_s[((long long)hpos * e.hist_stride + i) * 4 + j] = s0v[j];
                                     if (emit) s0v[j] = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * 4 + j);
@@ -485,7 +489,7 @@ k_actor(NetDims m, ActorArgs g) {
                         } else {
                             int a_row = act, d_row = dr.z != 0.0f ? 1 : 0;
                             float rew = dr.w;
-                            if (ns > 1) nstep_row(e, ns, hpos, hold, i, emit, a_row, rew, d_row);
+                            if constexpr (NSTEP) nstep_row(e, ns, hpos, hold, i, emit, a_row, rew, d_row);
                             if (emit) {
                                 *p_act = a_row;                                      // replay_buffer.py:60
                                 *p_rew = rew;                                        // :61
@@ -506,7 +510,7 @@ k_actor(NetDims m, ActorArgs g) {
                             const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
                             const float nx = ih_normal(o);
                             float s_row = lx[il * sx + el];
-                            if (ns > 1) {                                            // n-step: the row starts at the oldest step on file
+                            if constexpr (NSTEP) {                                            // n-step: the row starts at the oldest step on file
                                 e.hist_s[((long long)hpos * e.hist_stride + i) * D + el] = s_row;
                                 if (emit) s_row = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * D + el);
                             }
@@ -551,7 +555,7 @@ k_actor(NetDims m, ActorArgs g) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
             e.st->env_ctr = ec + (unsigned long long)g.T;
-            if (e.n_step > 1) e.st->hist_steps = hs0 + (unsigned long long)g.T;
+            if constexpr (NSTEP) e.st->hist_steps = hs0 + (unsigned long long)g.T;
             e.st->arrive = 0;
         }
     }
@@ -590,7 +594,10 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     }
     if (g.n_smp && lds < sizeof(float) * 528) lds = sizeof(float) * 528;
     const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
-#define ACTOR_CASE(K1, K2) if (KB == K1 && KB2 == K2) { DQN_LAUNCH((k_actor<K1, K2>), grid, block, lds, s, m, g); return; }
+#define ACTOR_CASE(K1, K2) if (KB == K1 && KB2 == K2) {                                                     \
+        if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true>), grid, block, lds, s, m, g);                      \
+        else DQN_LAUNCH((k_actor<K1, K2, false>), grid, block, lds, s, m, g);                                    \
+        return; }
     ACTOR_CASE(1, 4) ACTOR_CASE(2, 4) ACTOR_CASE(4, 4) ACTOR_CASE(8, 4) ACTOR_CASE(16, 4)
     ACTOR_CASE(1, 16) ACTOR_CASE(2, 16) ACTOR_CASE(4, 16) ACTOR_CASE(8, 16) ACTOR_CASE(16, 16)
 #undef ACTOR_CASE
