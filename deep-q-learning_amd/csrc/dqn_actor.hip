@@ -283,6 +283,8 @@ k_actor(NetDims m, ActorArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(whv[0]), "+v"(whv[1]), "+v"(whv[2]), "+v"(whv[3]) :: "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+        asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
+                                                 // where a full vmcnt wait would also wait for the previous step's ring stores)
         // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -536,7 +538,8 @@ k_actor(NetDims m, ActorArgs g) {
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes are done ...
-                    if (lane == 0) *reinterpret_cast<volatile int *>(lflag + (wave - 1)) = flagv;   // ... before its flag
+                    if (lane == 0) lflag[wave - 1] = flagv;                      // ... before its flag (a plain LDS store: a volatile
+                    asm volatile("" ::: "memory");                               // cast made it a flat store behind a full vmcnt wait)
                     if (t == 1) WSTAMP(28);
                 }
                 LDS_BARRIER();
@@ -590,7 +593,7 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
         const size_t nT = (size_t)T * (size_t)env.n;
         size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : RANGE_MAX) + 2) + 64);
         if (lds < need) lds = need;
-        if (env.rebuild_top) { need = sizeof(float) * ((size_t)1 << (env.L < PW_TOP ? env.L : PW_TOP)); if (lds < need) lds = need; }
+        if (env.rebuild_top) { need = sizeof(float) * (env.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << env.L); if (lds < need) lds = need; }
     }
     if (g.n_smp && lds < sizeof(float) * 528) lds = sizeof(float) * 528;
     const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);

@@ -594,7 +594,7 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
     const dim3 grid((B + 15) / 16 + extra, npass), block(256);
     size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 32 + 528);
     if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
-    if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * ((size_t)1 << (ea.L < PW_TOP ? ea.L : PW_TOP)); if (lds < need) lds = need; }
+    if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * (ea.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << ea.L); if (lds < need) lds = need; }
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
         FuseBwd fb{*fuse, tile_cnt, st};

@@ -23,6 +23,7 @@ NAMES = {0: ("k_qnet_fwd (+ fused row backward)", ["start", "x staged", "L1 done
          6: ("k_dw", ["start", "mfma loop done", "epilogue (adam) done", "end"]),
          7: ("k_actor (T=4)", ["start", "weights requested, x staged"] +
              [f"t{t} {w}" for t in range(4) for w in ("L1 done", "L2 done", "heads+policy done", "env done")]),
+         2: ("per_top_wg (tree workgroup of k_actor)", ["start", "depth-14 loads landed, depth 13 summed", "register tree written to the LDS image", "coalesced copy-out issued", "LDS levels done", "final drain"]),
          3: ("k_actor side chain (tree workgroup, then sampler workgroup 0)",
              ["tree wg start", "top rebuilt", "leaves inserted", "flag released", "sampler start", "flag seen", "acquired", "batch drawn"])}
 
