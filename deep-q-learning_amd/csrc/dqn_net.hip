@@ -189,9 +189,9 @@ struct MmaLayer {
         const float *arow = lds_a + (lane & 15) * stride + 4 * (lane >> 4);
         if constexpr (PP) {
             for (int kq0 = 0; kq0 < KQ; kq0 += 2 * PF) {
-                load(b1, kq0 + PF);
+                if (kq0 + PF < KQ) load(b1, kq0 + PF);               // (nothing to prefetch past the end: layer 1 of a small obs_dim is one chunk)
                 compute(b0, kq0, arow, acc);
-                load(b0, kq0 + 2 * PF);
+                if (kq0 + 2 * PF < KQ) load(b0, kq0 + 2 * PF);
                 compute(b1, kq0 + PF, arow, acc);
             }
         } else {
