@@ -37,6 +37,6 @@ for src, dst in ((f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc.json"),
                  (f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json")):
     if os.path.exists(src):
         shutil.copy(src, dst)
-for s in glob.glob("gpurun_out/sweep_*.json"):
+for s in glob.glob(f"gpurun_out/sweep_{tag}*.json"):
     shutil.copy(s, f"profiles/{rnd}_{os.path.basename(s)}")
 print(open(f"profiles/{rnd}_kernel_trace_one_step.csv").read())
