@@ -108,10 +108,10 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
         if (pack == h->pack) launch_pack(s, h->m, params, h->pack_act);   // the actor kernel reads f32 shadows of the online net
     } else launch_pack(s, h->m, params, pack);
 }
-static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const EnvArgs *env = nullptr,
-                  const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, env, smp, fuse, h->tile_cnt, h->st);
-    else launch_qnet_fwd(s, h->m, p, n, B, env, smp, fuse, h->tile_cnt, h->st);
+static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
+                  const BwdArgs *fuse = nullptr) {
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st);
+    else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -534,7 +534,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     const int grid_tiles = h->bf16 ? 2 * ((B + 31) / 32) : (B + 15) / 16;
     const bool fuse_rows = 3 * grid_tiles <= 256 && (presampled || !h->cfg.use_per) && !h->no_fuse_rows;
     arm(h);
-    L_fwd(h, st, p, 3, B, nullptr, &sm, fuse_rows ? &g : nullptr);
+    L_fwd(h, st, p, 3, B, &sm, fuse_rows ? &g : nullptr);
     mark(h, st, fuse_rows ? "sample_fwd_x3_bwd" : "sample_fwd_x3");
     if (!fuse_rows) {
         arm(h);
@@ -604,18 +604,10 @@ static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
     mark(h, st, "actor_steps");
 }
 
-// q_agent.py:176-183 for n_envs device-resident synthetic envs: two kernels
+// q_agent.py:176-183 for n_envs device-resident envs, one vector step: k_actor with T = 1 (forward + epsilon-greedy policy +
+// env transition + ring insert per 4-env workgroup, leaves inserted by the tree workgroup)
 static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuild_top = false) {
-    // ONE launch: forward + epsilon-greedy policy (:176), then per workgroup the synthetic transition, ring insert
-    // and state = observation of its 16 envs (:177-183); a surplus workgroup inserts the new leaves into the tree.
-    if (actor_multi_ok(h, n_envs, 1)) { enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0); return; }
-    // (n_step > 1 is k_actor only: dqn_create's capacity >= max_batch check below keeps actor_multi_ok true for one step)
-    FwdPass p = make_pass(h, DQN_NET_ONLINE, h->env_obs, nullptr, nullptr, false);
-    p.act_out = h->env_a; p.act_state = h->st; p.act_seed = h->cfg.seed;
-    const EnvArgs e = env_args(h, n_envs, rebuild_top);
-    arm(h);
-    L_fwd(h, st, &p, 1, n_envs, &e);
-    mark(h, st, "actor_step");
+    enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0);
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only)

@@ -82,8 +82,8 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
 // fuse != NULL (f32, three passes, 3 * ceil(B/16) <= 256, batch weights final before the launch): the pass-0 workgroups
 // also run the row backward of their tiles (k_bwd_rows' work); tile_cnt = ceil(B/16) zeroed counters
-void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
-                     const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
+                     const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
 // T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip
 bool actor_multi_supported(const NetDims &m, int n_envs, int T);
 void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
@@ -101,7 +101,6 @@ void launch_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L);
 void launch_adam(hipStream_t s, const NetDims &m, DqnState *st, float *params, const float *grad, float *mu,
                  float *nu, float *pack, int adamw, float b1, float b2, float eps, float wd, float grad_scale);
-void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *env_a);
 void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, unsigned long long seed,
                    unsigned long long ctr, int32_t *actions, const DqnState *st_from);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
@@ -111,8 +110,6 @@ void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *ac
                        float *observations, uint8_t *dones, long long N, int D, const float *s,
                        const int32_t *a, const float *r, const float *s2, const uint8_t *d, int n,
                        float *s_advance, int bump_env);
-void launch_synth_env(hipStream_t st_, const DqnState *st, int n, int D, unsigned long long seed, float p_done,
-                      float *obs_next, float *r, uint8_t *d);
 void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,
                            const float *rewards, const float *observations, const uint8_t *dones, int D,
                            int B, unsigned long long seed, unsigned long long ctr, int from_state,
@@ -134,8 +131,8 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 // ----- bf16 MFMA variants (dqn_net_bf16.hip); pointer fields typed float* carry bf16 data -------------
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
-void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env = nullptr,
-                          const SampleArgs *smp = nullptr, const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
+                          const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

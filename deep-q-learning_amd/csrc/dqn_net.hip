@@ -27,19 +27,6 @@ extern "C" int dqn_debug_stamps(unsigned long long *out_host) {
 }
 #endif
 
-// An actor launch (env.st != NULL) steps the device-resident synthetic envs in the same launch as the forward
-// pass (q_agent.py:176-183): the last workgroup in x is surplus and inserts the new leaves into the sum-tree,
-// every other workgroup writes the transitions of its own 16 envs after choosing their actions.
-#define ACTOR_PROLOGUE(LDSPTR)                                                                          \
-    const bool actor = env.st != nullptr;                                                               \
-    unsigned long long env_c0 = 0, env_ec = 0;                                                          \
-    if (actor) { env_c0 = env.st->ring_counter; env_ec = env.st->env_ctr; }                             \
-    if (actor && env.tree && blockIdx.x == gridDim.x - 1) {                                             \
-        actor_tree_wg(env, env_c0, reinterpret_cast<float *>(LDSPTR));                                  \
-        actor_commit(env, env_c0, env_ec, gridDim.x);                                                   \
-        return;                                                                                         \
-    }
-
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // position of column c (0..15) inside its 16-block of an LDS A-operand row: the lane group
@@ -239,9 +226,8 @@ struct FwdPasses { FwdPass p[3]; };
 
 template <int TN1, int TN2, bool FUSE>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp, FuseBwd fb) {
+k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    ACTOR_PROLOGUE(lds)
     const FwdPass ps = passes.p[blockIdx.y];
     const int tile = blockIdx.x, row0 = tile * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -443,14 +429,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp, Fuse
             const unsigned long long ctr = ps.act_state ? ps.act_state->env_ctr : ps.act_ctr;
             const int act = policy_row(qrow, m.A, eps, ps.act_seed, ctr, row0 + tid);
             ps.act_out[row0 + tid] = act;
-            if (actor) reinterpret_cast<int *>(lh + 256)[tid] = act;
         }
-    }
-    if (actor) {
-        LDS_BARRIER();
-        const int cnt = row0 < B ? (B - row0 < 16 ? B - row0 : 16) : 0;
-        env_rows(tid, 256, row0, cnt, env_c0, env_ec, env, m.D, reinterpret_cast<const int32_t *>(lh + 256), row0);
-        actor_commit(env, env_c0, env_ec, gridDim.x);
     }
     STAMP(0, 6);
     if constexpr (FUSE) {
@@ -584,28 +563,24 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, EnvArgs env, SampleArgs smp, Fuse
 
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
 
-void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
-                     const SampleArgs *smp, const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
+void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
+                     const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
     FwdPasses ps{};
     for (int i = 0; i < npass; ++i) ps.p[i] = passes[i];
-    const EnvArgs ea = env ? *env : EnvArgs{};
     const SampleArgs sa = smp ? *smp : SampleArgs{};
-    const int extra = (env && env->tree) ? 1 : 0;                       // surplus workgroup: leaf-range insert
-    const dim3 grid((B + 15) / 16 + extra, npass), block(256);
+    const dim3 grid((B + 15) / 16, npass), block(256);
     size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 32 + 528);
-    if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
-    if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * (ea.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << ea.L); if (lds < need) lds = need; }
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
         FuseBwd fb{*fuse, tile_cnt, st};
         lds += sizeof(float) * (16 * (m.H2 + 4) + 16);
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, true>), grid, block, lds, s, m, ps, B, ea, sa, fb); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, true>), grid, block, lds, s, m, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
         FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
     }
     const FuseBwd fb{};
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, false>), grid, block, lds, s, m, ps, B, ea, sa, fb); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, false>), grid, block, lds, s, m, ps, B, sa, fb); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE

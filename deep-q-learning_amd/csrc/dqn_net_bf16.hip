@@ -10,19 +10,6 @@
 #include "dqn_net_common.h"
 #include "dqn_per_device.h"
 
-// An actor launch (env.st != NULL) steps the device-resident synthetic envs in the same launch as the forward
-// pass (q_agent.py:176-183): the last workgroup in x is surplus and inserts the new leaves into the sum-tree,
-// every other workgroup writes the transitions of its own 16 envs after choosing their actions.
-#define ACTOR_PROLOGUE(LDSPTR)                                                                          \
-    const bool actor = env.st != nullptr;                                                               \
-    unsigned long long env_c0 = 0, env_ec = 0;                                                          \
-    if (actor) { env_c0 = env.st->ring_counter; env_ec = env.st->env_ctr; }                             \
-    if (actor && env.tree && blockIdx.x == gridDim.x - 1) {                                             \
-        actor_tree_wg(env, env_c0, reinterpret_cast<float *>(LDSPTR));                                  \
-        actor_commit(env, env_c0, env_ec, gridDim.x);                                                   \
-        return;                                                                                         \
-    }
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -154,9 +141,8 @@ struct FwdPasses16 { FwdPass p[3]; };
 // once the other two passes have handed over their Q rows (L1-bypassing stores, drained, then the tile's counter)
 template <int TN1, int TN2, bool FUSE>
 __global__ void __launch_bounds__(256)
-k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, SampleArgs smp, FuseBwd fb) {
+k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, FuseBwd fb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ACTOR_PROLOGUE(smem)
     const FwdPass ps = passes.p[blockIdx.y];
     const __bf16 *pack = reinterpret_cast<const __bf16 *>(ps.pack);
     __bf16 *px = reinterpret_cast<__bf16 *>(ps.px), *ph1 = reinterpret_cast<__bf16 *>(ps.ph1), *ph2 = reinterpret_cast<__bf16 *>(ps.ph2);
@@ -342,14 +328,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
             const unsigned long long ctr = ps.act_state ? ps.act_state->env_ctr : ps.act_ctr;
             const int act = policy_row(qrow, m.A, eps, ps.act_seed, ctr, row0 + tid);
             ps.act_out[row0 + tid] = act;
-            if (actor) reinterpret_cast<int *>(lh + 256)[tid] = act;
         }
-    }
-    if (actor) {
-        LDS_BARRIER();
-        const int cnt = row0 < B ? (B - row0 < 16 ? B - row0 : 16) : 0;
-        env_rows(tid, 256, row0, cnt, env_c0, env_ec, env, m.D, reinterpret_cast<const int32_t *>(lh + 256), row0);
-        actor_commit(env, env_c0, env_ec, gridDim.x);
     }
     if constexpr (FUSE) {
         if (blockIdx.y != 0) {
@@ -477,30 +456,26 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, EnvArgs env, Sample
 // tiles are launched in pairs so that every 32-row k-block of the batch-major stashes is fully written
 static inline int tiles16(int B) { return 2 * ((B + 31) / 32); }
 
-void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const EnvArgs *env,
-                          const SampleArgs *smp, const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
+void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
+                          const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
     FwdPasses16 ps{};
     bool stash = false;
     for (int i = 0; i < npass; ++i) { ps.p[i] = passes[i]; stash |= passes[i].px != nullptr; }
     const Dims16 d = make_dims16(m);
-    const EnvArgs ea = env ? *env : EnvArgs{};
     const SampleArgs sa = smp ? *smp : SampleArgs{};
-    const int extra = (env && env->tree) ? 1 : 0;
-    const dim3 grid((stash ? tiles16(B) : (B + 15) / 16) + extra, npass), block(256);
+    const dim3 grid(stash ? tiles16(B) : (B + 15) / 16, npass), block(256);
     size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 32 + 528);
-    if (extra && lds < sizeof(float) * (2 * (size_t)(ea.n + 2) + 64)) lds = sizeof(float) * (2 * (size_t)(ea.n + 2) + 64);
-    if (extra && ea.rebuild_top) { const size_t need = sizeof(float) * (ea.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << ea.L); if (lds < need) lds = need; }
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
         const FuseBwd fb{*fuse, tile_cnt, st};
         lds += 2 * 16 * (d.KQH * 32 + 8) + 4 * 16;
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, true>), grid, block, lds, s, m, d, ps, B, ea, sa, fb); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, true>), grid, block, lds, s, m, d, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
         FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE
     }
     const FuseBwd fb{};
-#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, false>), grid, block, lds, s, m, d, ps, B, ea, sa, fb); return; }
+#define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, false>), grid, block, lds, s, m, d, ps, B, sa, fb); return; }
     FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
     FWD_CASE(4, 1) FWD_CASE(4, 2) FWD_CASE(4, 4)
 #undef FWD_CASE

@@ -116,8 +116,7 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
 
 
 // ------------------------------------------------------------ synthetic env + leaf-range insert
-// Shared by k_env_step / k_per_add (dqn_replay.hip) and the actor variant of the forward kernels, where
-// every forward workgroup steps its own 16 envs and one surplus workgroup inserts the new leaves.
+// Shared by k_per_add (dqn_replay.hip) and k_actor (dqn_actor.hip), whose tree workgroup inserts the new leaves.
 #define RANGE_MAX 4096
 
 struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic envs; st == NULL => not an actor launch
@@ -167,61 +166,10 @@ __device__ __forceinline__ bool cartpole_step(float (&s)[4], int action) {
     s[3] = s[3] + 0.02f * thetaacc;
     return s[0] < -2.4f || s[0] > 2.4f || s[2] < -0.20943951f || s[2] > 0.20943951f;
 }
-// one thread per env of [i0, i0+cnt): physics, ring row, episode bookkeeping, auto-reset
-__device__ __forceinline__ void cartpole_rows(int tr, int nthr, int i0, int cnt, unsigned long long c0, unsigned long long ec,
-                                              const EnvArgs &e, const int32_t *acts, int acts_base) {
-    for (int il = tr; il < cnt; il += nthr) {
-        const int i = i0 + il;
-        const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)e.cap);
-        float s[4];
-        for (int j = 0; j < 4; ++j) { s[j] = e.env_obs[(long long)i * 4 + j]; e.states[k * 4 + j] = s[j]; }
-        const int a = acts[i - acts_base];
-        const bool term = cartpole_step(s, a);
-        const int t = e.env_t[i] + 1;
-        const bool done = term || t >= e.max_steps;                      // q_agent.py:179-180
-        for (int j = 0; j < 4; ++j) e.observations[k * 4 + j] = s[j];
-        e.actions[k] = a; e.rewards[k] = term ? e.term_reward : 1.0f; e.dones[k] = done ? 1 : 0;
-        if (done) {
-            atomicAdd(&e.st->ep_count, 1ull);
-            atomicAdd(&e.st->ep_steps, (unsigned long long)t);
-            const u32x4 o = philox_draw(e.seed, ec, (uint32_t)i, DQN_STREAM_ENV);
-            s[0] = (u01(o.x) * 0.1f) - 0.05f; s[1] = (u01(o.y) * 0.1f) - 0.05f;
-            s[2] = (u01(o.z) * 0.1f) - 0.05f; s[3] = (u01(o.w) * 0.1f) - 0.05f;
-        }
-        e.env_t[i] = done ? 0 : t;
-        for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = s[j];
-    }
-}
-
 
 // a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3) -- exactly reproducible on the CPU
 __device__ __forceinline__ float ih_normal(const u32x4 o) {
     return (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;
-}
-
-// synthetic transition + ReplayBuffer.add + state = observation for envs [i0, i0+cnt); one work item per
-// (env, element): elements 0..D-1 are the next observation, element D is (reward, done). Thread `tr` of `nthr`.
-__device__ __forceinline__ void env_rows(int tr, int nthr, int i0, int cnt, unsigned long long c0, unsigned long long ec,
-                                         const EnvArgs &e, int D, const int32_t *acts, int acts_base) {
-    if (e.kind == 1) { cartpole_rows(tr, nthr, i0, cnt, c0, ec, e, acts, acts_base); return; }
-    for (int t = tr; t < cnt * (D + 1); t += nthr) {
-        const int il = t / (D + 1), el = t - il * (D + 1), i = i0 + il;
-        const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)e.cap);
-        const u32x4 o = philox_draw(e.seed, ec, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
-        if (el < D) {
-            const float nx = ih_normal(o);
-            e.states[k * D + el] = e.env_obs[(long long)i * D + el];        // replay_buffer.py:59
-            e.observations[k * D + el] = nx;                                // :62
-            e.env_obs[(long long)i * D + el] = nx;                          // q_agent.py:183
-        } else {
-            const bool done = u01(o.x) < e.p_done;
-            float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
-            if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
-            e.actions[k] = acts[i - acts_base];                             // :60
-            e.rewards[k] = rew;                                             // :61
-            e.dones[k] = done ? 1 : 0;                                      // :63
-        }
-    }
 }
 
 // level-synchronous fallback through global memory (ring wrap, or n > RANGE_MAX). Whole workgroup.
@@ -403,33 +351,6 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
         LDS_BARRIER();
     }
     __syncthreads();                                         // drain this workgroup's tree stores before it re-reads them
-}
-
-// ---- actor launch helpers (forward kernel + env step in one launch)
-// surplus workgroup: the leaf-range insert of this vector step (independent of the actions: new leaves get pmax)
-__device__ __forceinline__ void actor_tree_wg(const EnvArgs &e, unsigned long long c0, float *lds) {
-    // deferred rebuild of the tree top after the previous update's priority write-back: this workgroup is the next
-    // reader of those nodes (boundary siblings of the range insert), and it has slack behind the forward workgroups
-    if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
-    const float pmax = e.st->pmax;
-    const long long a = (long long)(c0 % (unsigned long long)e.cap);
-    if (e.n <= RANGE_MAX && a + e.n <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, e.n, pmax, lds);
-    else per_add_slow(e.tree, e.Nt, e.L, c0, e.n, pmax, e.cap);
-}
-// the last workgroup of the launch to arrive commits the counters (every thread's stores depend on c0 / ec, so a
-// workgroup that reaches its barrier has finished reading them; no fence is needed for that)
-__device__ __forceinline__ void actor_commit(const EnvArgs &e, unsigned long long c0, unsigned long long ec, unsigned total_wgs) {
-    LDS_BARRIER();
-    if (threadIdx.x == 0) {
-        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
-        if (ticket == total_wgs - 1u) {
-            const unsigned long long c1 = c0 + (unsigned long long)e.n;
-            e.st->ring_counter = c1;                                                            // replay_buffer.py:64
-            e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
-            e.st->env_ctr = ec + 1ull;
-            e.st->arrive = 0;
-        }
-    }
 }
 
 // ------------------------------------------------------------ sampling fused into the forward launch

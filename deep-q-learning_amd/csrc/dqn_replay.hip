@@ -55,23 +55,6 @@ k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, floa
 // (+-100 on terminals), d ~ Bernoulli(p_done), all from Philox stream 3 and exactly
 // reproducible on the CPU: a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3).
 
-__global__ void __launch_bounds__(256)
-k_synth_env(const DqnState *st, int n, int D, unsigned long long seed, float p_done,
-            float *obs_next, float *r, uint8_t *d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long c = st->env_ctr;
-    const uint32_t base = (uint32_t)i * (uint32_t)(D + 1);
-    for (int e = 0; e < D; ++e)
-        obs_next[(long long)i * D + e] = ih_normal(philox_draw(seed, c, base + (uint32_t)e, DQN_STREAM_ENV));
-    const u32x4 o = philox_draw(seed, c, base + (uint32_t)D, DQN_STREAM_ENV);
-    const bool done = u01(o.x) < p_done;
-    float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
-    if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
-    r[i] = rew;
-    d[i] = done ? 1 : 0;
-}
-
 // ------------------------------------------------------------- uniform sampling
 // sample_batch (replay_buffer.py:68-85): indices (given, or Philox stream 1) + 5 gathers.
 // One thread per sampled row; a row's D floats are contiguous.
@@ -473,30 +456,6 @@ k_per_add(const DqnState *st, float *tree, long long Nt, int L, int n, long long
     else per_add_slow(tree, Nt, L, c_base, n, pmax, cap);
 }
 
-// ------------------------------------------------------------- vector env step, one workgroup
-// q_agent.py:177-183 for n synthetic envs given their actions: synthetic transition, ReplayBuffer.add of the
-// n rows, state = observation, and -- with PER -- the leaf-range insert. (The device-resident actor loop uses
-// the fused forward+env launch instead; this kernel serves env steps whose actions come from elsewhere.)
-__global__ void __launch_bounds__(1024)
-k_env_step(EnvArgs e, int D, const int32_t *env_a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
-    const float pmax = e.st->pmax;
-    const long long a = (long long)(c0 % (unsigned long long)e.cap);
-    env_rows(tid, blockDim.x, 0, e.n, c0, ec, e, D, env_a, 0);
-    if (e.tree) {
-        if (e.n <= RANGE_MAX && a + e.n <= e.cap) per_add_range_wg(e.tree, e.Nt, e.L, a, e.n, pmax, lds);
-        else per_add_slow(e.tree, e.Nt, e.L, c0, e.n, pmax, e.cap);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long c1 = c0 + (unsigned long long)e.n;
-        e.st->ring_counter = c1;                                                            // :64
-        e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
-        e.st->env_ctr = ec + 1ull;
-    }
-}
 
 // --------------------------------------------------------------------- launchers
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
@@ -511,10 +470,6 @@ void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *ac
                        observations, dones, N, D, s, a, r, s2, d, n, s_advance, bump_env);
 }
 
-void launch_synth_env(hipStream_t st_, const DqnState *st, int n, int D, unsigned long long seed, float p_done,
-                      float *obs_next, float *r, uint8_t *d) {
-    hipLaunchKernelGGL(k_synth_env, dim3((n + 255) / 256), dim3(256), 0, st_, st, n, D, seed, p_done, obs_next, r, d);
-}
 
 void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *states, const int32_t *actions,
                            const float *rewards, const float *observations, const uint8_t *dones, int D,
@@ -565,10 +520,6 @@ void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long 
     hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, st, tree, Nt, L, n, cap);
 }
 
-void launch_env_step(hipStream_t st_, const EnvArgs &e, int D, const int32_t *env_a) {
-    const size_t lds = (e.tree && e.n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(e.n + 2) + 64) : 0;
-    DQN_LAUNCH(k_env_step, dim3(1), dim3(pow2_threads(e.n * (D + 1), 64, 1024)), lds, st_, e, D, env_a);
-}
 
 void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
     const int TOP = L < PW_TOP ? L : PW_TOP;
