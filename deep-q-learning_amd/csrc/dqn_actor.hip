@@ -13,6 +13,9 @@
 //   * the two skinny heads (4 rows x (1+A) columns, K = H2) run as 4*(1+A) VALU fmaf chains out of LDS;
 //   * the env state never leaves LDS between steps; ring rows go straight to their (deterministic) slots
 //     counter + t*n + i (replay_buffer.py:58-65).
+// Synthetic env: no physics. Per env i and vector step c: obs' ~ N(0,1)^D, r ~ N(0,1) (+-100 on terminals),
+// d ~ Bernoulli(p_done), all from Philox stream 3 and exactly reproducible on the CPU (a normal is the Irwin-Hall sum
+// ((u0+u1)+(u2+u3) - 2) * sqrt(3)). CartPole-v1: dqn_per_device.h.
 // Riding in the same launch, off the actors' critical path:
 //   * workgroup 0 rebuilds the tree top left stale by the previous update's priority write-back and inserts the
 //     T*n new leaves (all at the running max priority, one contiguous range), then releases a flag;

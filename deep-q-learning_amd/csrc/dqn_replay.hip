@@ -50,11 +50,6 @@ k_replay_add(DqnState *st, float *states, int32_t *actions, float *rewards, floa
     }
 }
 
-// ---------------------------------------------------------------- synthetic env
-// no physics. Per env i and vector step c: obs' ~ N(0,1)^D, r ~ N(0,1)
-// (+-100 on terminals), d ~ Bernoulli(p_done), all from Philox stream 3 and exactly
-// reproducible on the CPU: a normal is the Irwin-Hall sum ((u0+u1)+(u2+u3) - 2) * sqrt(3).
-
 // ------------------------------------------------------------- uniform sampling
 // sample_batch (replay_buffer.py:68-85): indices (given, or Philox stream 1) + 5 gathers.
 // One thread per sampled row; a row's D floats are contiguous.
