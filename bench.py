@@ -130,7 +130,7 @@ def prefill(eng, gen):
         eng.per_set(idx, pr)
 
 
-def cpu_baseline(seconds=12.0):
+def cpu_baseline(seconds=float(os.environ.get("DQN_BENCH_CPU_SECONDS", "12"))):
     """The oracle's plain-C restatement (oracle/, kind "port") timed on this host, single thread, on a
     bounded sample of the same workload: same shapes, ring 2^20, same step definition."""
     sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]

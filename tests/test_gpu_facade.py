@@ -187,3 +187,30 @@ def test_agent_training_loop_and_checkpoint(ref, tmp_path):
     params3, st3 = ref["generate_loading"](str(tmp_path / "ckpt2"))()
     assert torch.equal(params3.flat, agent._params.flat) and st3[0].count == agent.updates
     assert torch.equal(st3[0].nu.flat, agent._opt_state[0].nu.flat)
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(torch_cuda):
+    """bench.py (short run): stdout is exactly ONE JSON line carrying the driver's contract fields, `roofline` and
+    `cpu_baseline`; native libraries' chatter must not reach stdout"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DQN_BENCH_CPU_SECONDS="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "60", "--warmup", "20", "--profile-steps", "2",
+                          "--no-secondary"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 60 and d["warmup"] == 20 and d["n_gpus"] == 1 and d["value"] > 1000 and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
