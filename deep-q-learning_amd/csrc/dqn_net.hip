@@ -334,6 +334,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
     {
         f32x4 acc[TN1];
         L1.finish(lx, sx, lane, acc);
+        STAMP(0, 11);
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int ct = wave + 4 * t;
@@ -352,7 +353,9 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
             }
         }
     }
+    STAMP(0, 12);
     if (wave == 0) LH.template load_range<0, 16>();          // heads' weights: wave 0 only, 16 requests
+    STAMP(0, 13);
     LDS_BARRIER();
     STAMP(0, 2);
 

@@ -55,6 +55,9 @@ def main():
         print(f"k_actor step 1, wave 1 (real-time ns since the step's L2 done): draws start {int(st[7, 27, 1] - st[7, 7, 1]) * 10}, "
               f"flag written {int(st[7, 28, 1] - st[7, 7, 1]) * 10}; wave 0: chain done {int(st[7, 25, 1] - st[7, 7, 1]) * 10}, "
               f"flags seen {int(st[7, 26, 1] - st[7, 7, 1]) * 10}, phase end {int(st[7, 8, 1] - st[7, 7, 1]) * 10}")
+    if st[0, 11, 0]:
+        print("k_qnet_fwd layer-1 phase (cycles since x staged): " + ", ".join(
+            f"{lab} +{int(st[0, i, 0] - st[0, 1, 0])}" for lab, i in (("MFMAs done", 11), ("epilogue stores issued", 12), ("head weights requested", 13), ("barrier passed", 2))))
     for k, (name, labels) in NAMES.items():
         t = st[k, :len(labels)]
         cyc = t[:, 0] - t[0, 0]; real = (t[:, 1] - t[0, 1]) * 10.0     # ns
