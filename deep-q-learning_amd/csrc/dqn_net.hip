@@ -317,14 +317,12 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         if (t < 16 * K1) {
             const int rl = t / K1, c = t - rl * K1;
             lx[rl * sx + (c & ~15) + perm16(c & 15)] = xv[u];
-            if (ps.px) ps.px[pidx(KQb, row0 + rl, c)] = xv[u];
         }
     }
     for (int t = tid + 1024; t < 16 * K1; t += 256) {            // obs_dim > 64 only
         const int rl = t / K1, c = t - rl * K1;
         const float v = xload(t);
         lx[rl * sx + (c & ~15) + perm16(c & 15)] = v;
-        if (ps.px) ps.px[pidx(KQb, row0 + rl, c)] = v;
     }
     LDS_BARRIER();
     STAMP(0, 1);
@@ -348,7 +346,6 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                     v = v > 0.0f ? v : 0.0f;
                     if constexpr (FUSE) m1bits |= (v > 0.0f ? 1u : 0u) << (4 * t + r);
                     l1[rl * s1 + 16 * ct + perm16(c)] = v;
-                    if (ps.ph1) ps.ph1[pfrag(KQb, tile, ct, r, lane)] = v;
                 }
             }
         }
@@ -377,7 +374,6 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                     v = v > 0.0f ? v : 0.0f;
                     if constexpr (FUSE) m2bits |= (v > 0.0f ? 1u : 0u) << (4 * t + r);
                     l2[rl * s2 + 16 * ct + perm16(c)] = v;
-                    if (ps.ph2) ps.ph2[pfrag(KQb, tile, ct, r, lane)] = v;
                     if (ps.feat && row0 + rl < B) ps.feat[(long long)(row0 + rl) * m.H2 + col] = v;   // :32-33
                 }
             }
@@ -386,6 +382,24 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
     LDS_BARRIER();
     STAMP(0, 4);
 
+    // The batch-major stashes of x / h1 / h2 for k_dw (pass 0 of an update): written now, out of the LDS images, by the
+    // three waves that would idle behind the heads -- one 16-B store per four rows of a column (the operand order of
+    // k_dw: float4 number (ct*KQb + tile)*64 + lane' holds rows 4j + (lane'>>4), j = 0..3, of column 16ct + (lane'&15))
+    // instead of one 4-B store per accumulator element inside the layer epilogues, where they queued behind the
+    // weight prefetch.
+    if (ps.px && wave != 0) {
+        auto stash = [&](float *dst, const float *img, int stride, int CT) {
+            float4 *out = reinterpret_cast<float4 *>(dst);
+            for (int q = tid - 64; q < CT * 64; q += 192) {
+                const int ct = q >> 6, lp = q & 63;
+                const float *col = img + (lp >> 4) * stride + 16 * ct + perm16(lp & 15);
+                out[(long long)(ct * KQb + tile) * 64 + lp] = float4{col[0], col[4 * stride], col[8 * stride], col[12 * stride]};
+            }
+        };
+        stash(ps.px, lx, sx, m.KQ1);
+        stash(ps.ph1, l1, s1, m.H1 / 16);
+        stash(ps.ph2, l2, s2, m.H2 / 16);
+    }
     // heads: column 0 = val (dddqn.py:29), columns 1..A = adv (:30); one 16-column tile
     if (wave == 0) {
         f32x4 acc[1];
