@@ -28,6 +28,10 @@
 #include "dqn_net_common.h"
 
 #define MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define MFMA4B(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ short bf16_bits(float f) { return __builtin_bit_cast(short, (__bf16)f); }   // round to nearest even
+__device__ __forceinline__ s16x4 cvt4(float a, float b, float c, float d) { return s16x4{bf16_bits(a), bf16_bits(b), bf16_bits(c), bf16_bits(d)}; }
 
 #ifdef DQN_STAMPS
 extern __device__ unsigned long long g_stamps[8][64][2];
@@ -144,7 +148,10 @@ __device__ __forceinline__ void nstep_row(const EnvArgs &e, int ns, int hpos, in
 // x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
 // KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
 // NSTEP: dqn_config.n_step > 1 (compiled apart: the n-step bookkeeping costs scalar registers in the step loop)
-template <int KB, int KB2, bool NSTEP>
+// BF: bf16 mode (DQN_PREC_BF16) -- the same workgroup / step structure on v_mfma_f32_4x4x4_16b_bf16: weights and
+// activations rounded to bf16 (as the update's bf16 kernels do), f32 accumulation, FOUR k per instruction, so every
+// K-long chain is a quarter as long; the slabs are converted once per launch from the f32 shadows
+template <int KB, int KB2, bool NSTEP, bool BF>
 __global__ void __launch_bounds__(256)
 k_actor(NetDims m, ActorArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -216,6 +223,10 @@ k_actor(NetDims m, ActorArgs g) {
         int *lt = reinterpret_cast<int *>(lq + 64);                          // CartPole step counters of the tile
         float *lrand = lq + 64 + 4;                                          // [4][4]: policy u, random action, done, reward
         int *lflag = reinterpret_cast<int *>(lrand + 16);                    // [3] (+1 pad, 16-B aligned): draws of waves 1..3 are in LDS
+        // bf16 mode: bf16 images of h1 / h2 / the heads' weights (rounded ONCE, by the lanes that produce them: a chain link
+        // is then one 8-B LDS read + one MFMA, no conversion in its shadow)
+        const int s1h = 16 * KB + 8, s2h = 16 * KB2 + 8;
+        __bf16 *l1h = reinterpret_cast<__bf16 *>(lflag + 4), *l2h = l1h + 4 * s1h, *lwh16 = l2h + 4 * s2h;
         const float *P = g.params;
         const int r4 = lane & 3;
         ASTAMP(0);
@@ -278,6 +289,7 @@ k_actor(NetDims m, ActorArgs g) {
         ASTAMP(20);
         // zero images: h1 / h2 columns past hidden1 / hidden2 and the heads' padding stay zero for the whole launch
         for (int t = tid; t < 4 * s1 + 4 * s2 + (A + 1) * s2; t += 256) l1[t] = 0.0f;
+        if constexpr (BF) for (int t = tid; t < 4 * s1h + 4 * s2h + (A + 1) * s2h; t += 256) l1h[t] = (__bf16)0.0f;
         if (tid < 3) lflag[tid] = 0;
         LDS_BARRIER();
         ASTAMP(21);
@@ -297,6 +309,12 @@ k_actor(NetDims m, ActorArgs g) {
                 if (4 + gq <= A) lwh[(4 + gq) * s2 + k] = whv[u][1];
                 if (8 + gq <= A) lwh[(8 + gq) * s2 + k] = whv[u][2];
                 if (12 + gq <= A) lwh[(12 + gq) * s2 + k] = whv[u][3];
+                if constexpr (BF) {
+                    if (gq <= A) lwh16[gq * s2h + k] = (__bf16)whv[u][0];
+                    if (4 + gq <= A) lwh16[(4 + gq) * s2h + k] = (__bf16)whv[u][1];
+                    if (8 + gq <= A) lwh16[(8 + gq) * s2h + k] = (__bf16)whv[u][2];
+                    if (12 + gq <= A) lwh16[(12 + gq) * s2h + k] = (__bf16)whv[u][3];
+                }
             }
         }
         if (tid < 4 * sx) lx[tid] = x0;                                      // first tile's rows
@@ -307,6 +325,14 @@ k_actor(NetDims m, ActorArgs g) {
         // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
         const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
         bool w2_landed = false;
+        s16x4 w1p[4], w2p[BF ? 4 * KB : 1];                               // bf16 mode: the slabs as four-k bf16 groups
+        float bh16 = 0.0f;                                               // bf16 mode: head bias of column `lane` (wave 0)
+        if constexpr (BF) {
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) w1p[kq] = cvt4(w1r[4 * kq], w1r[4 * kq + 1], w1r[4 * kq + 2], w1r[4 * kq + 3]);
+            if (wave == 0 && lane <= A) bh16 = lane == 0 ? P[m.o_bv] : P[m.o_ba + lane - 1];
+            asm volatile("" : "+v"(bh16));                               // (tracked load: waited for here, not in the step loop)
+        }
         const int hpos0 = NSTEP ? (int)(hs0 % (unsigned long long)e.n_step) : 0;   // one 64-bit modulo per launch, not per step
 
         for (int tile = wg; tile < g.tiles; tile += g.G) {
@@ -334,14 +360,38 @@ k_actor(NetDims m, ActorArgs g) {
                 const int flagv = (tile - wg) / g.G * g.T + t + 1;              // value the draw flags take in this step
                 // The slabs live in registers for the whole launch: the empty asm makes their values opaque here, so
                 // the compiler can neither re-request them from memory inside the step loop nor forget them.
+                if constexpr (BF) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+                    for (int kq = 0; kq < 4; ++kq) asm volatile("" : "+v"(w1p[kq]));
+                    asm volatile("" : "+v"(bh16));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+                }
                 asm volatile("" : "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(eps));
                 // layer 1: h1 = relu(x @ w1 + b1)                              dddqn.py:25-26
                 {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const float *ar = lx + r4 * sx;
-                    if (D <= 16) {
+                    if constexpr (BF) {
+                        if (D <= 16) {
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq) {
+                                if (4 * kq < DP) {
+                                    const float4 a4 = *reinterpret_cast<const float4 *>(ar + 4 * kq);
+                                    acc = MFMA4B(cvt4(a4.x, a4.y, a4.z, a4.w), w1p[kq], acc);
+                                }
+                            }
+                        } else {
+                            for (int k0 = 0; k0 < D; k0 += 4) {                 // (padding columns of lx are zero)
+                                const float4 a4 = *reinterpret_cast<const float4 *>(ar + k0);
+                                float wv[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) wv[u] = k0 + u < D ? P[m.o_w1 + (long long)(k0 + u) * H1 + cc1] : 0.0f;
+                                acc = MFMA4B(cvt4(a4.x, a4.y, a4.z, a4.w), cvt4(wv[0], wv[1], wv[2], wv[3]), acc);
+                            }
+                        }
+                    } else if (D <= 16) {
                         float4 ab[4];
 #pragma unroll
                         for (int kq = 0; kq < 4; ++kq) ab[kq] = *reinterpret_cast<const float4 *>(ar + (4 * kq < DP ? 4 * kq : 0));
@@ -359,20 +409,58 @@ k_actor(NetDims m, ActorArgs g) {
                     }
                     if (col < (unsigned)H1) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float v = acc[r] + b1r; l1[r * s1 + col] = v > 0.0f ? v : 0.0f; }
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[r] + b1r;
+                            if constexpr (BF) l1h[r * s1h + col] = (__bf16)(v > 0.0f ? v : 0.0f);
+                            else l1[r * s1 + col] = v > 0.0f ? v : 0.0f;
+                        }
                     }
                 }
-                if (!w2_landed) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2_landed = true; ASTAMP(24); }
+                if (!w2_landed) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2_landed = true; ASTAMP(24);
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int kq = 0; kq < 4 * KB; ++kq) {
+                            if (kq < 16) asm volatile("" : "+v"(w2q[kq])); else asm volatile("" : "+a"(w2q[kq]));
+                            w2p[kq] = cvt4(w2q[kq][0], w2q[kq][1], w2q[kq][2], w2q[kq][3]);
+                        }
+                    }
+                }
                 LDS_BARRIER();
                 ASTAMP(2 + 4 * t);
+                if constexpr (BF) {
 #pragma unroll
-                for (int kq = 0; kq < 4 * KB; ++kq) {
-                    if (kq < 16) asm volatile("" : "+v"(w2q[kq]));
-                    else asm volatile("" : "+a"(w2q[kq]));
+                    for (int kq = 0; kq < 4 * KB; ++kq) asm volatile("" : "+v"(w2p[kq]));
+                } else {
+#pragma unroll
+                    for (int kq = 0; kq < 4 * KB; ++kq) {
+                        if (kq < 16) asm volatile("" : "+v"(w2q[kq]));
+                        else asm volatile("" : "+a"(w2q[kq]));
+                    }
                 }
                 // layer 2: h2 = relu(h1 @ w2 + b2)                             dddqn.py:27-28
                 // A operand (4 consecutive k of this lane's row) read from LDS four groups ahead of its MFMAs
-                {
+                if constexpr (BF) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const s16x4 *ar = reinterpret_cast<const s16x4 *>(l1h + r4 * s1h);      // four consecutive k of this lane's row
+                    s16x4 ab[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ab[q] = ar[q];
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const s16x4 a4 = ab[u];
+                            if (kb + 1 < KB) ab[u] = ar[4 * (kb + 1) + u];
+                            acc = MFMA4B(a4, w2p[4 * kb + u], acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (col < (unsigned)H2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float v = acc[r] + b2r; l2h[r * s2h + col] = (__bf16)(v > 0.0f ? v : 0.0f); }
+                    }
+                } else {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const float *ar = l1 + r4 * s1;
                     float4 ab[4];
@@ -405,7 +493,30 @@ k_actor(NetDims m, ActorArgs g) {
                     long long pk = at + pil; if (pk >= e.cap) pk -= e.cap;
                     int32_t *p_act = e.actions + pk; float *p_rew = e.rewards + pk; uint8_t *p_done = e.dones + pk;
                     // heads (dddqn.py:29-30): 4 rows x (1+A) columns = 4*(1+A) fmaf chains over hidden2, one per lane
-                    if (hlane) {
+                    if constexpr (BF) {
+                        // bf16 mode: one 4x4x4 chain for all of them -- lane l supplies column l of [wv|wa] (lanes past 1+A:
+                        // a duplicate of column A, result unused) and row l&3 of h2; acc[r] of lane l = head l of row r
+                        const int hcl = lane <= A ? lane : A;
+                        const s16x4 *ar = reinterpret_cast<const s16x4 *>(l2h + (lane & 3) * s2h), *wr = reinterpret_cast<const s16x4 *>(lwh16 + hcl * s2h);
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        s16x4 ab[4], wb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { ab[q] = ar[q]; wb[q] = wr[q]; }
+#pragma unroll
+                        for (int kb = 0; kb < KB2; ++kb) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const s16x4 a4 = ab[q], w4 = wb[q];
+                                if (kb + 1 < KB2) { ab[q] = ar[4 * (kb + 1) + q]; wb[q] = wr[4 * (kb + 1) + q]; }
+                                acc = MFMA4B(a4, w4, acc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        if (lane <= A) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) lq[r * 16 + lane] = acc[r] + bh16;
+                        }
+                    } else if (hlane) {
                         const float *ar = l2 + hr * s2, *wr = lwh + hc * s2;
                         float acc = 0.0f;
                         float4 ab[4], wb[4];
@@ -574,7 +685,7 @@ bool actor_multi_supported(const NetDims &m, int n_envs, int T) {
 }
 
 void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
-                        int32_t *act_out, int B, const SampleArgs *smp) {
+                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16) {
     ActorArgs g{};
     g.env = env; g.T = T; g.params = params; g.pack = pack; g.act_out = act_out;
     // the register-resident weight slab limits a CU to ONE workgroup of this kernel, whatever its role: keep the
@@ -592,6 +703,7 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     const int KB2 = m.H2 <= 64 ? 4 : 16;
     size_t lds = sizeof(float) * (4 * (size_t)(DP + 4) + 4 * (size_t)(16 * KB + 4) + 4 * (size_t)(16 * KB2 + 4) +
                                   (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 16 + 4);
+    if (bf16) lds += 2 * (4 * (size_t)(16 * KB + 8) + (size_t)(m.A + 5) * (16 * KB2 + 8));
     if (g.n_tree) {
         const size_t nT = (size_t)T * (size_t)env.n;
         size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : RANGE_MAX) + 2) + 64);
@@ -601,8 +713,10 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     if (g.n_smp && lds < sizeof(float) * 528) lds = sizeof(float) * 528;
     const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
 #define ACTOR_CASE(K1, K2) if (KB == K1 && KB2 == K2) {                                                     \
-        if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true>), grid, block, lds, s, m, g);                      \
-        else DQN_LAUNCH((k_actor<K1, K2, false>), grid, block, lds, s, m, g);                                    \
+        if (bf16) { if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true, true>), grid, block, lds, s, m, g);    \
+                    else DQN_LAUNCH((k_actor<K1, K2, false, true>), grid, block, lds, s, m, g); }                \
+        else { if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true, false>), grid, block, lds, s, m, g);        \
+               else DQN_LAUNCH((k_actor<K1, K2, false, false>), grid, block, lds, s, m, g); }                    \
         return; }
     ACTOR_CASE(1, 4) ACTOR_CASE(2, 4) ACTOR_CASE(4, 4) ACTOR_CASE(8, 4) ACTOR_CASE(16, 4)
     ACTOR_CASE(1, 16) ACTOR_CASE(2, 16) ACTOR_CASE(4, 16) ACTOR_CASE(8, 16) ACTOR_CASE(16, 16)

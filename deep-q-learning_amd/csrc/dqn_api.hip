@@ -85,6 +85,7 @@ struct dqn_handle {
     float *hist_s = nullptr, *hist_r = nullptr; int32_t *hist_a = nullptr, *hist_d = nullptr;   // n-step history
     int n_step = 1; float gamma_n = 0.0f;
     bool no_fuse_rows = getenv("DQN_NO_FUSE_ROWS") != nullptr;    // diagnostic: keep k_bwd_rows as its own launch
+    bool f32_actor = getenv("DQN_BF16_F32_ACTOR") != nullptr;     // diagnostic: bf16 mode with the exact-f32 actor chain
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
@@ -598,9 +599,10 @@ static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
     sm.st = h->st; sm.tree = h->tree; sm.N = h->Ntree; sm.L = h->L; sm.seed = h->cfg.seed;
     sm.idx = h->bidx; sm.w_raw = h->bw_raw;
     arm(h);
-    // bf16 mode: the actor forward stays exact f32 on the master weights (latency-bound at 4 rows per workgroup: the
-    // f32 matrix-core chain costs the same time), reading its two f32 shadows from pack_act
-    launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm);
+    // bf16 mode: the same kernel on v_mfma_f32_4x4x4_16b_bf16 (weights / activations rounded to bf16 in registers from
+    // the f32 shadows in pack_act: chains a quarter as long)
+    launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm,
+                       h->bf16 && !h->f32_actor);
     mark(h, st, "actor_steps");
 }
 

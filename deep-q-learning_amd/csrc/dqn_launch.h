@@ -87,7 +87,7 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
 // T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip
 bool actor_multi_supported(const NetDims &m, int n_envs, int T);
 void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
-                        int32_t *act_out, int B, const SampleArgs *smp);
+                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16 = false);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
                const float *r, const float *d, const float *isw, float gamma, int B, int A,
                float *targets, float *td, float *dq, float *loss, float *scratch);

@@ -164,3 +164,31 @@ def test_fused_row_backward_equals_separate_launch(dq, precision, monkeypatch):
     assert np.array_equal(out[True][1], out[False][1])
     assert out[True][2] == out[False][2] and np.isfinite(out[True][2])
 
+
+def test_bf16_actor_chain_agrees_with_the_bf16_forward(dq):
+    """bf16 mode's k_actor (v_mfma_f32_4x4x4_16b_bf16 chains, weights / activations rounded to bf16 in registers) must act
+    like the bf16 forward kernel: with epsilon = 0 the chosen action is the argmax of dqn_qnet_forward's Q, except where
+    the two best actions are closer than the bf16 tolerance; and it must differ from the f32 master weights' Q by no more
+    than that tolerance allows (i.e. it is not silently the f32 chain)"""
+    import torch
+    dims = CFGS["cfg2"]
+    n = 256
+    e = mk(dq, dims, capacity=1 << 12, use_per=True, max_batch=1024, seed=3)
+    P0 = rand_params(dims, 10)
+    e.set_params(P0); e.sync_target()
+    obs = np.random.default_rng(5).standard_normal((n, 8)).astype(np.float32)
+    q_api = host(e.forward(obs))                                   # bf16 forward kernel
+    e.env_reset(obs, 0.01); e.set_epsilon(0.0)
+    with torch.cuda.stream(e.stream):
+        e.actor_step()
+        e.stream.synchronize()
+    acts = host(e.buffer(dq._lib.BUF_ENV_ACTIONS, torch.int32))[:n]
+    top2 = np.sort(q_api, axis=1)[:, -2:]
+    gap = top2[:, 1] - top2[:, 0]
+    scale = np.abs(q_api).max()
+    clear = gap > 2e-2 * scale
+    assert clear.sum() > n // 2
+    assert np.array_equal(acts[clear], q_api.argmax(1)[clear])
+    assert np.array_equal(acts, host(e.buffer(dq._lib.BUF_ACTIONS, torch.int32))[:n])      # the ring got the same actions
+    e.close()
+

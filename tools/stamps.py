@@ -30,7 +30,8 @@ NAMES = {0: ("k_qnet_fwd (+ fused row backward)", ["start", "x staged", "L1 done
 
 def main():
     eng = dq.Engine(dq.EngineConfig(obs_dim=bench.D, hidden1=bench.H1, hidden2=bench.H2, num_actions=bench.A,
-                                    capacity=1 << bench.LOG2N, use_per=True, max_batch=bench.B, seed=1))
+                                    capacity=1 << bench.LOG2N, use_per=True, max_batch=bench.B, seed=1,
+                                    precision=os.environ.get("DQN_STAMPS_PRECISION", "f32")))
     gen = torch.Generator(device=eng.device); gen.manual_seed(0)
     eng.set_params(torch.randn(eng.param_count) * 0.05); eng.sync_target()
     bench.prefill(eng, gen)
