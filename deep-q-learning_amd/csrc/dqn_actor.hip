@@ -60,6 +60,7 @@ struct ActorArgs {
     const float *pack;           // their packed shadows (p_w2k: k-packed W2, p_wht: heads)
     int32_t *act_out;            // [n] actions of the last step
     int tiles, G;                // 4-env tiles, actor workgroups (tile = wg, wg + G, ...)
+    int TC;                      // steps whose Philox draws are made at once (what the LDS draw buffer holds)
     int n_tree, n_smp;           // role split of the grid: [tree][actors x G][samplers x n_smp]
     int B; SampleArgs smp;       // presampling of the next update's batch (n_smp > 0)
 };
@@ -221,12 +222,15 @@ k_actor(NetDims m, ActorArgs g) {
         const int sx = DP + 4, s1 = 16 * KB + 4, s2 = 16 * KB2 + 4;
         float *lx = lds, *l1 = lx + 4 * sx, *l2 = l1 + 4 * s1, *lwh = l2 + 4 * s2, *lq = lwh + (A + 1) * s2;
         int *lt = reinterpret_cast<int *>(lq + 64);                          // CartPole step counters of the tile
-        float *lrand = lq + 64 + 4;                                          // [4][4]: policy u, random action, done, reward
-        int *lflag = reinterpret_cast<int *>(lrand + 16);                    // [3] (+1 pad, 16-B aligned): draws of waves 1..3 are in LDS
+        // Philox draws of TC steps at a time, [TC][4 envs][DW]: the synthetic env's next observation (D floats), then the
+        // policy's u, its random action, done, reward. None depends on the forward pass: waves 1..3 make them for a whole
+        // chunk of steps up front (behind the W2 stream for the first tile) instead of inside every step.
+        const int DO = (D + 3) & ~3, DW = DO + 4;                            // the four scalars sit 16-B aligned behind the observation
+        float *ldraw = lq + 64 + 4;
         // bf16 mode: bf16 images of h1 / h2 / the heads' weights (rounded ONCE, by the lanes that produce them: a chain link
         // is then one 8-B LDS read + one MFMA, no conversion in its shadow)
         const int s1h = 16 * KB + 8, s2h = 16 * KB2 + 8;
-        __bf16 *l1h = reinterpret_cast<__bf16 *>(lflag + 4), *l2h = l1h + 4 * s1h, *lwh16 = l2h + 4 * s2h;
+        __bf16 *l1h = reinterpret_cast<__bf16 *>(ldraw + g.TC * 4 * DW), *l2h = l1h + 4 * s1h, *lwh16 = l2h + 4 * s2h;
         const float *P = g.params;
         const int r4 = lane & 3;
         ASTAMP(0);
@@ -286,11 +290,40 @@ k_actor(NetDims m, ActorArgs g) {
         // of the slab requests, the compiler would put a full wait in front of that request)
         asm volatile("" :: "v"(vx), "v"(v1), "v"(v2), "v"(vh), "v"(vq[0]), "v"(vq[1]), "v"(vq[2]), "v"(vq[3]));
         float eps = e.st->epsilon;
+        // ---- Philox draws of steps t0 .. t0+TC-1 of a tile (waves 1..3): for the first tile right here, while the parameter
+        // requests above are in flight
+        auto make_draws = [&](int i0, int cnt, int t0) {
+            if (wave == 0) return;
+            const int nobs = e.kind == 0 ? cnt * D : 0, per = nobs + 2 * cnt;
+            const int nst = g.T - t0 < g.TC ? g.T - t0 : g.TC;
+            for (int u = tid - 64; u < nst * per; u += 192) {
+                const int ts = u / per, v = u - ts * per;
+                const unsigned long long ecs = ec + (unsigned long long)(t0 + ts);
+                float *dw = ldraw + (ts * 4) * DW;
+                if (v < nobs) {
+                    const int il = v / D, el = v - il * D, i = i0 + il;
+                    dw[il * DW + el] = ih_normal(philox_draw(e.seed, ecs, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV));
+                } else if (v < nobs + cnt) {
+                    const int il = v - nobs, i = i0 + il;
+                    const u32x4 o = philox_draw(e.seed, ecs, (uint32_t)i, DQN_STREAM_POLICY);   // as policy_row()
+                    dw[il * DW + DO] = u01(o.x);
+                    dw[il * DW + DO + 1] = __int_as_float((int)(((unsigned long long)o.y * (unsigned long long)A) >> 32));
+                } else if (e.kind == 0) {
+                    const int il = v - nobs - cnt, i = i0 + il;
+                    const u32x4 o = philox_draw(e.seed, ecs, (uint32_t)(i * (D + 1) + D), DQN_STREAM_ENV);
+                    const bool done = u01(o.x) < e.p_done;
+                    float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
+                    if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
+                    dw[il * DW + DO + 2] = done ? 1.0f : 0.0f;
+                    dw[il * DW + DO + 3] = rew;
+                }
+            }
+        };
+        if (wg < g.tiles) make_draws(4 * wg, e.n - 4 * wg < 4 ? e.n - 4 * wg : 4, 0);
         ASTAMP(20);
         // zero images: h1 / h2 columns past hidden1 / hidden2 and the heads' padding stay zero for the whole launch
         for (int t = tid; t < 4 * s1 + 4 * s2 + (A + 1) * s2; t += 256) l1[t] = 0.0f;
         if constexpr (BF) for (int t = tid; t < 4 * s1h + 4 * s2h + (A + 1) * s2h; t += 256) l1h[t] = (__bf16)0.0f;
-        if (tid < 3) lflag[tid] = 0;
         LDS_BARRIER();
         ASTAMP(21);
         // the small operands are the youngest requests: everything issued so far has landed after this wait; the registers
@@ -348,6 +381,8 @@ k_actor(NetDims m, ActorArgs g) {
             ASTAMP(1);
 
             for (int t = 0; t < g.T; ++t) {
+                if (t % g.TC == 0 && !(tile == wg && t == 0)) make_draws(i0, cnt, t);   // (first chunk of the first tile: made in the prologue)
+                const float *dstep = ldraw + ((t % g.TC) * 4) * DW;
                 const bool last = t == g.T - 1;
                 const unsigned long long ect = ec + (unsigned long long)t;
                 const bool emit = !NSTEP || t >= warm;                          // (n-step warm-up: the step is only filed)
@@ -357,7 +392,6 @@ k_actor(NetDims m, ActorArgs g) {
                 if constexpr (NSTEP) { hpos = hpos0 + t; hpos -= hpos >= ns ? ns : 0; hpos -= hpos >= ns ? ns : 0;   // (hpos0 < ns, t < 64: loop below)
                               while (hpos >= ns) hpos -= ns;
                               hold = hpos + 1 == ns ? 0 : hpos + 1; }
-                const int flagv = (tile - wg) / g.G * g.T + t + 1;              // value the draw flags take in this step
                 // The slabs live in registers for the whole launch: the empty asm makes their values opaque here, so
                 // the compiler can neither re-request them from memory inside the step loop nor forget them.
                 if constexpr (BF) {
@@ -539,13 +573,7 @@ k_actor(NetDims m, ActorArgs g) {
                         lq[hr * 16 + hc] = acc + bh;
                     }
                     if (t == 1) ASTAMP(25);
-                    // the random draws of this step were made by waves 1..3 meanwhile
-                    for (;;) {                                                    // one 16-B LDS read per poll
-                        asm volatile("" ::: "memory");                            // re-read
-                        const int4 fl = *reinterpret_cast<const int4 *>(lflag);
-                        if (fl.x == flagv && fl.y == flagv && fl.z == flagv) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order (lq)
                     if (t == 1) ASTAMP(26);
                     if (lane < cnt) {
                         // dueling combine (dddqn.py:31) + epsilon-greedy (q_agent.py:137-141, compute_action :70)
@@ -553,7 +581,7 @@ k_actor(NetDims m, ActorArgs g) {
                         // (the 16 head outputs and the draws in registers after ONE LDS latency; unrolled, no indexed arrays)
                         const float4 *hrow = reinterpret_cast<const float4 *>(lq + il * 16);
                         const float4 h0 = hrow[0], h1 = hrow[1], h2 = hrow[2], h3 = hrow[3];
-                        const float4 dr = *reinterpret_cast<const float4 *>(lrand + il * 4);
+                        const float4 dr = *reinterpret_cast<const float4 *>(dstep + il * DW + DO);   // u, random action, done, reward
                         const float h[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
                         float sum = 0.0f;
 #pragma unroll
@@ -614,47 +642,25 @@ k_actor(NetDims m, ActorArgs g) {
                         }
                     }
                 } else {
-                    // waves 1..3, meanwhile: every Philox draw of the step (none depends on the forward pass) -- the
-                    // policy's (u, random action), and for the synthetic env the next observations (written to the ring
-                    // and to the LDS state right here) and the (reward, done) pairs
-                    if (t == 1) WSTAMP(27);
+                    // waves 1..3, meanwhile: the synthetic env's transition of this step out of the draw buffer (ring rows,
+                    // LDS state); nothing to do for CartPole, whose transition depends on the action (wave 0 above)
                     const int nobs = e.kind == 0 ? cnt * D : 0;
-                    for (int u = tid - 64; u < nobs + 2 * cnt; u += 192) {
-                        if (u < nobs) {
-                            const int il = u / D, el = u - il * D, i = i0 + il;
-                            long long k = at + il; if (k >= e.cap) k -= e.cap;
-                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV);
-                            const float nx = ih_normal(o);
-                            float s_row = lx[il * sx + el];
-                            if constexpr (NSTEP) {                                            // n-step: the row starts at the oldest step on file
-                                e.hist_s[((long long)hpos * e.hist_stride + i) * D + el] = s_row;
-                                if (emit) s_row = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * D + el);
-                            }
-                            if (emit) {
-                                e.states[k * D + el] = s_row;                        // replay_buffer.py:59
-                                e.observations[k * D + el] = nx;                     // :62
-                            }
-                            lx[il * sx + el] = nx;                                   // q_agent.py:183 (read by this thread only)
-                            if (last) e.env_obs[(long long)i * D + el] = nx;
-                        } else if (u < nobs + cnt) {
-                            const int il = u - nobs, i = i0 + il;
-                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)i, DQN_STREAM_POLICY);   // as policy_row()
-                            lrand[il * 4 + 0] = u01(o.x);
-                            lrand[il * 4 + 1] = __int_as_float((int)(((unsigned long long)o.y * (unsigned long long)A) >> 32));
-                        } else if (e.kind == 0) {
-                            const int il = u - nobs - cnt, i = i0 + il;
-                            const u32x4 o = philox_draw(e.seed, ect, (uint32_t)(i * (D + 1) + D), DQN_STREAM_ENV);
-                            const bool done = u01(o.x) < e.p_done;
-                            float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
-                            if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
-                            lrand[il * 4 + 2] = done ? 1.0f : 0.0f;
-                            lrand[il * 4 + 3] = rew;
+                    for (int u = tid - 64; u < nobs; u += 192) {
+                        const int il = u / D, el = u - il * D, i = i0 + il;
+                        long long k = at + il; if (k >= e.cap) k -= e.cap;
+                        const float nx = dstep[il * DW + el];
+                        float s_row = lx[il * sx + el];
+                        if constexpr (NSTEP) {                                            // n-step: the row starts at the oldest step on file
+                            e.hist_s[((long long)hpos * e.hist_stride + i) * D + el] = s_row;
+                            if (emit) s_row = ld_sc1(e.hist_s + ((long long)hold * e.hist_stride + i) * D + el);
                         }
+                        if (emit) {
+                            e.states[k * D + el] = s_row;                        // replay_buffer.py:59
+                            e.observations[k * D + el] = nx;                     // :62
+                        }
+                        lx[il * sx + el] = nx;                                   // q_agent.py:183 (read by this thread only)
+                        if (last) e.env_obs[(long long)i * D + el] = nx;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes are done ...
-                    if (lane == 0) lflag[wave - 1] = flagv;                      // ... before its flag (a plain LDS store: a volatile
-                    asm volatile("" ::: "memory");                               // cast made it a flat store behind a full vmcnt wait)
-                    if (t == 1) WSTAMP(28);
                 }
                 LDS_BARRIER();
                 ASTAMP(4 + 4 * t);
@@ -702,7 +708,12 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     const int KB = m.H1 <= 16 ? 1 : (m.H1 <= 32 ? 2 : (m.H1 <= 64 ? 4 : (m.H1 <= 128 ? 8 : 16)));
     const int KB2 = m.H2 <= 64 ? 4 : 16;
     size_t lds = sizeof(float) * (4 * (size_t)(DP + 4) + 4 * (size_t)(16 * KB + 4) + 4 * (size_t)(16 * KB2 + 4) +
-                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 16 + 4);
+                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4);
+    const int DWh = ((m.D + 3) & ~3) + 4;
+    g.TC = 6144 / (4 * DWh);                                              // draw buffer: <= 24 KB
+    if (g.TC > T) g.TC = T;
+    if (g.TC < 1) g.TC = 1;
+    lds += sizeof(float) * (size_t)g.TC * 4 * DWh;
     if (bf16) lds += 2 * (4 * (size_t)(16 * KB + 8) + (size_t)(m.A + 5) * (16 * KB2 + 8));
     if (g.n_tree) {
         const size_t nT = (size_t)T * (size_t)env.n;
