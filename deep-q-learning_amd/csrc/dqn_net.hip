@@ -1011,7 +1011,7 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     if (ad.P) {
         // commit the optimizer counters once every block has read them (its element updates above
         // depend on the coefficients, so passing this barrier implies the reads are complete)
-        __syncthreads();
+        LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
         if (tid == 0) {
             const unsigned int ticket = atomicAdd(&st->arrive, 1u);
             if (ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
@@ -1045,7 +1045,7 @@ k_adam(NetDims m, DqnState *st, float *P, const float *__restrict__ g, float *mu
     }
     // commit the step counters once every block has read them: a thread's stores above depend on
     // the coefficients, so passing this barrier implies its reads of the state are complete.
-    __syncthreads();
+    LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
     if (threadIdx.x == 0) {
         const unsigned int ticket = atomicAdd(&st->arrive, 1u);
         if (ticket == gridDim.x - 1) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }

@@ -736,7 +736,7 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
         }
     }
     if (ad.P) {
-        __syncthreads();
+        LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
         if (tid == 0) {
             const unsigned int ticket = atomicAdd(&st->arrive, 1u);
             if (ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
@@ -768,7 +768,7 @@ k_adam16(NetDims m, Dims16 d, DqnState *st, float *P, const float *__restrict__ 
         scatter_packs16(m, d, i, p, pack);
         if (pack_act) scatter_actor_packs(m, i, p, pack_act);
     }
-    __syncthreads();
+    LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
     if (threadIdx.x == 0) {
         const unsigned int ticket = atomicAdd(&st->arrive, 1u);
         if (ticket == gridDim.x - 1) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
