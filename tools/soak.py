@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Soak test of the captured inner loop (both precision modes, bench shape): tens of thousands of graph replays with the
+in-launch hand-overs (tree workgroup -> samplers in k_actor, Q rows -> pass-0 workgroup in the forward launch). A hand-over
+that ever timed out poisons the loss with NaN; the sum-tree invariant is checked along the way.
+    python tools/soak.py [--seconds 40]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import deep_q_learning_amd as dq  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=40.0); args = ap.parse_args()
+    for prec in ("f32", "bf16"):
+        e = dq.Engine(dq.EngineConfig(obs_dim=bench.D, hidden1=bench.H1, hidden2=bench.H2, num_actions=bench.A, capacity=1 << bench.LOG2N,
+                                      use_per=True, max_batch=bench.B, seed=7, precision=prec))
+        gen = torch.Generator(device=e.device); gen.manual_seed(0)
+        e.set_params(bench.init_params(e.param_count)); e.sync_target()
+        bench.prefill(e, gen)
+        e.env_reset(torch.randn(bench.N_ENVS, bench.D, device=e.device, generator=gen), 0.01); e.set_epsilon(0.15)
+        N = 1 << bench.LOG2N
+        k = torch.arange(1, N, device=e.device)
+        t0 = time.time(); iters = 0; checks = 0
+        with torch.cuda.stream(e.stream):
+            while time.time() - t0 < args.seconds:
+                for _ in range(50):
+                    e.train_iters(20, 4, bench.B, e.stream)
+                iters += 1000
+                e.stream.synchronize()
+                loss = float(e.last_loss().item())
+                assert loss == loss, f"{prec}: NaN loss after {iters} iterations (a hand-over timed out?)"
+                if iters % 20000 == 0:
+                    t = e.buffer(dq._lib.BUF_TREE)
+                    bad = (t[k] != t[2 * k] + t[2 * k + 1]).nonzero()
+                    assert bad.numel() == 0, (prec, iters, bad[:4].flatten().tolist())
+                    checks += 1
+                    e.sync_target()
+        assert e.opt_count() == iters
+        print(f"{prec}: {iters} iterations in {time.time() - t0:.1f} s ({iters / (time.time() - t0):.0f}/s incl. checks), loss {loss:.4f}, "
+              f"{checks} tree checks ok", flush=True)
+        e.close()
+
+
+if __name__ == "__main__":
+    main()
