@@ -22,10 +22,12 @@
 //   * ceil(B/16) sampler workgroups wait for that flag and draw the NEXT update's stratified PER batch (indices, raw
 //     IS weights, batch max) -- the tree is final once the leaves are in, whatever the actors are still doing; the
 //     sampled rows themselves are gathered by the forward launch that follows (SampleArgs.pre).
+#include <type_traits>
 #include "dqn_device.h"
 #include "dqn_launch.h"
 #include "dqn_per_device.h"
 #include "dqn_net_common.h"
+#include <cstdlib>
 
 #define MFMA1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -61,51 +63,96 @@ struct ActorArgs {
     int32_t *act_out;            // [n] actions of the last step
     int tiles, G;                // 4-env tiles, actor workgroups (tile = wg, wg + G, ...)
     int TC;                      // steps whose Philox draws are made at once (what the LDS draw buffer holds)
-    int n_tree, n_smp;           // role split of the grid: [tree][actors x G][samplers x n_smp]
+    int n_tree, n_smp, NR;                 // NR: batch rows per sampler lane group (1, 2, 4)           // role split of the grid: [tree][actors x G][samplers x n_smp]
     int B; SampleArgs smp;       // presampling of the next update's batch (n_smp > 0)
 };
 
 // ---- one sampler workgroup: 16 batch rows, 16 lanes per row, 4 tree levels per memory round trip (the descent of
 // sample_tile_coop in dqn_per_device.h: same compares / subtractions in the same order, hence the same leaves)
-__device__ __forceinline__ void presample_tile(const SampleArgs &s, int row0, int B, int tid, long long size,
-                                               float *lsub, float *lw) {
-    const int g = tid >> 4, j = tid & 15;
-    const int k = row0 + g, kk = k < B ? k : B - 1;
+// the stratified uniforms of rows row0 + 16 r + g, before scaling by the tree total: k + u01 (they depend on nothing
+// the launch changes, so a sampler workgroup draws them while it waits for the tree)
+template <int NR>
+__device__ __forceinline__ void presample_draw(const SampleArgs &s, int row0, int B, int tid, float (&uu)[NR]) {
+    const int g = tid >> 4;
     const unsigned long long ctr = s.st->sample_ctr;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int k = row0 + 16 * r + g, kk = k < B ? k : B - 1;
+        const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
+        uu[r] = (float)kk + u01(o.x);
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void presample_tile(const SampleArgs &s, int row0, int B, int tid, long long size,
+                                               float *lsub, float *lw, const float (&uu)[NR], int sb = -1) {
+#define PSTAMP(i) do { if (sb >= 0) BSTAMP(sb + (i)); } while (0)
+    // 16 lanes per descent, 4 tree levels per round trip; NR descents per lane group in flight together (rows
+    // row0 + 16 r + g) when the batch has more 16-row tiles than the launch has sampler workgroups
+    const int g = tid >> 4, j = tid & 15;
     const float beta = s.st->beta;
     const float total = s.tree[1];
     const float seg = __fdiv_rn(total, (float)B);
-    const u32x4 o = philox_draw(s.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
-    float u = ((float)kk + u01(o.x)) * seg;
-    long long cur = 1;
+    int k[NR];
+    float u[NR];
+    long long cur[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        k[r] = row0 + 16 * r + g;
+        u[r] = uu[r] * seg;
+        cur[r] = 1;
+    }
+    PSTAMP(0);
     float *sub = lsub + g * 32;
     for (int done = 0; done < s.L; done += 4) {
         const int nl = s.L - done < 4 ? s.L - done : 4;
         const int cnt = (2 << nl) - 2;
-        for (int f = j; f < cnt; f += 16) {
-            const int t = 31 - __clz(f + 2), i = f + 2 - (1 << t);
-            sub[f] = s.tree[(cur << t) + i];
-        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            for (int f = j; f < cnt; f += 16) {
+                const int t = 31 - __clz(f + 2), i = f + 2 - (1 << t);
+                sub[r * 512 + f] = s.tree[(cur[r] << t) + i];
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // a row group lives inside one wave
-        int p = 0;
-        for (int t = 1; t <= nl; ++t) {
-            const float l = sub[(1 << t) - 2 + 2 * p];
-            if (u < l) { p = 2 * p; }
-            else { u = u - l; p = 2 * p + 1; }
+        int p[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) p[r] = 0;
+        for (int t = 1; t <= nl; ++t) {                                   // the NR walks side by side: their LDS reads overlap
+            float l[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) l[r] = sub[r * 512 + (1 << t) - 2 + 2 * p[r]];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (u[r] < l[r]) { p[r] = 2 * p[r]; }
+                else { u[r] = u[r] - l[r]; p[r] = 2 * p[r] + 1; }
+            }
         }
-        cur = (cur << nl) + p;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cur[r] = (cur[r] << nl) + p[r];
+        PSTAMP(1 + (done >> 2));
     }
-    long long leaf = cur - s.N;
-    if (leaf >= size) leaf = size - 1;
     if (j == 0) {
-        const float w = pow_det(__fdiv_rn((float)size * s.tree[s.N + leaf], total), -beta);
-        lw[g] = k < B ? w : 0.0f;
-        if (k < B) { s.idx[k] = (int32_t)leaf; s.w_raw[k] = w; }
+        long long leaf[NR];
+        float pr[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            leaf[r] = cur[r] - s.N;
+            if (leaf[r] >= size) leaf[r] = size - 1;
+            pr[r] = s.tree[s.N + leaf[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float w = pow_det(__fdiv_rn((float)size * pr[r], total), -beta);
+            lw[16 * r + g] = k[r] < B ? w : 0.0f;
+            if (k[r] < B) { s.idx[k[r]] = (int32_t)leaf[r]; s.w_raw[k[r]] = w; }
+        }
     }
+    PSTAMP(6);
     LDS_BARRIER();
+    PSTAMP(7);
     if (tid == 0) {
         float mx = 0.0f;
-        for (int q = 0; q < 16; ++q) mx = fmaxf(mx, lw[q]);
+        for (int q = 0; q < 16 * NR; ++q) mx = fmaxf(mx, lw[q]);
         atomicMax(reinterpret_cast<unsigned int *>(&s.st->wmax), __float_as_uint(mx));
     }
 }
@@ -145,6 +192,92 @@ __device__ __forceinline__ void nstep_row(const EnvArgs &e, int ns, int hpos, in
     a = a0; r = acc; d = dn;
 }
 
+// ---- the side workgroups of an actor launch (shared by k_actor and k_actor16). role 0: the tree workgroup -- deferred top
+// rebuild, then the leaves of all steps of the launch (q_agent.py:182 x T; pmax only moves in a priority write-back, so the
+// T inserts of the sequential loop are one range insert), then the flag; role 2: a sampler workgroup -- q_agent.py:147-153
+// for the update that follows this launch, once the flag is up.
+__device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArgs &g, unsigned long long c0, unsigned long long nT,
+                                                unsigned long long c1, unsigned long long ticket_val, float *lds) {
+    const EnvArgs &e = g.env;
+    const int tid = threadIdx.x;
+    // the new slots are one contiguous leaf range, or two when the ring wraps (any order of inserting gives the same tree:
+    // a parent is always the sum of its two current children)
+    const long long a = (long long)(c0 % (unsigned long long)e.cap);
+    const long long seg_a[2] = {a, 0};
+    const long long seg_n[2] = {a + (long long)nT < e.cap ? (long long)nT : e.cap - a, a + (long long)nT < e.cap ? 0 : a + (long long)nT - e.cap};
+    // A single CU stores at ~7 B/clk: a long insert by the tree workgroup alone would be the launch's critical path
+    // (16 384 leaves: 37 us). With sampler workgroups in the launch, THEY store the inner nodes of the new range (closed
+    // form pmax * 2^level, no dependencies) before they wait for the flag; the tree workgroup only walks the end nodes.
+    // When the tree top is rebuilt in this launch, both stop at the top's base depth: the rebuild then derives everything
+    // above from final values.
+    const int TOPD = e.L < PW_TOP ? e.L : PW_TOP;
+    const int lmax = e.rebuild_top ? e.L - TOPD : e.L;                   // levels (leaf = 0) written by fill / end-node walk
+    // enough fillers to spread the stores (one per 512 leaves, <= 32), few enough that their counter bumps -- device-scope
+    // atomics on one line, ~0.1 us each -- stay short
+    int nfill = (int)(nT >> 9);
+    nfill = nfill < 1 ? 1 : (nfill > 32 ? 32 : nfill);
+    if (nfill > g.n_smp) nfill = g.n_smp;
+    if (role == 0) {
+        BSTAMP(0);
+        const float pmax = e.st->pmax;
+        if (g.n_smp > 0) {
+            for (int seg = 0; seg < 2; ++seg)
+                if (seg_n[seg] > 0) per_add_range_ends(e.tree, e.Nt, e.L, lmax, seg_a[seg], (int)seg_n[seg], pmax, lds);
+            BSTAMP(1);
+            // every sampler workgroup has stored (and released) its share of the inner nodes?
+            if (tid == 0)
+                while (__hip_atomic_load(&e.st->fill_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nfill) __builtin_amdgcn_s_sleep(4);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
+            BSTAMP(2);
+            __syncthreads();                                                 // every wave's tree stores (sc1) have been acknowledged
+            if (tid == 0) __hip_atomic_store(&e.st->tree_ready, ticket_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
+            BSTAMP(1);
+            for (int seg = 0; seg < 2; ++seg)
+                if (seg_n[seg] > 0) { per_add_range_wg(e.tree, e.Nt, e.L, seg_a[seg], (int)seg_n[seg], pmax, lds); __syncthreads(); }
+            BSTAMP(2);
+        }
+        BSTAMP(3);
+    } else if (role == 2) {
+        // ---- sampler workgroup: its share of the new leaves' inner nodes, then q_agent.py:147-153 for the update that follows
+        if (wg == 0) BSTAMP(4);
+        if (wg < nfill) {
+            const float pmax = e.st->pmax;
+            for (int seg = 0; seg < 2; ++seg)
+                if (seg_n[seg] > 0) per_add_range_fill(e.tree, e.Nt, lmax, seg_a[seg], (int)seg_n[seg], pmax, wg, nfill);
+            __syncthreads();                                                 // the stores (sc1) have been acknowledged
+            if (tid == 0) atomicAdd(&e.st->fill_cnt, 1u);
+        }
+        const long long size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);
+        auto run = [&](auto nr_tag) {
+            constexpr int NR = decltype(nr_tag)::value;
+            const int rows = 16 * NR, ntile = (g.B + rows - 1) / rows;
+            float uu[NR];
+            int tile = wg;
+            if (tile < ntile) presample_draw<NR>(g.smp, tile * rows, g.B, tid, uu);
+            if (tid == 0)
+                while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket_val)
+                    __builtin_amdgcn_s_sleep(8);                             // (hundreds of pollers of one line: poll sparsely; acquire below)
+            if (wg == 0) BSTAMP(5);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (wg == 0) BSTAMP(6);
+            for (; tile < ntile; tile += g.n_smp) {
+                presample_tile<NR>(g.smp, tile * rows, g.B, tid, size, lds, lds + 2048, uu, wg == 0 && tile == 0 ? 8 : -1);
+                LDS_BARRIER();                                               // lw is rewritten by the next tile
+                if (tile + g.n_smp < ntile) presample_draw<NR>(g.smp, (tile + g.n_smp) * rows, g.B, tid, uu);
+            }
+        };
+        if (g.NR == 1) run(std::integral_constant<int, 1>{});
+        else if (g.NR == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 4>{});
+        if (wg == 0) BSTAMP(7);
+    }
+}
+
 // KB = 16-row k-blocks of the register-resident W2 slab: hidden1 <= 16*KB (columns / rows past hidden1 are zeros, and
 // x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
 // KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
@@ -171,50 +304,8 @@ k_actor(NetDims m, ActorArgs g) {
     if ((int)blockIdx.x < g.n_tree) role = 0;
     else if (wg >= g.G) { role = 2; wg -= g.G; }
 
-    if (role == 0) {
-        // ---- tree workgroup: deferred top rebuild, then the leaves of all T steps (q_agent.py:182 x T; pmax only moves
-        // in a priority write-back, so the T inserts of the sequential loop are one range insert)
-        BSTAMP(0);
-        if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
-        BSTAMP(1);
-        const float pmax = e.st->pmax;
-        const long long a = (long long)(c0 % (unsigned long long)e.cap);
-        // the new slots are one contiguous leaf range, or two when the ring wraps; each is inserted in pieces of at most
-        // RANGE_MAX leaves (the LDS budget of per_add_range_wg). Any order gives the same tree: a parent is always the
-        // sum of its two current children.
-        for (int seg = 0; seg < 2; ++seg) {
-            const long long s0 = seg == 0 ? a : 0;
-            const long long s1 = seg == 0 ? (a + (long long)nT < e.cap ? a + (long long)nT : e.cap) : a + (long long)nT - e.cap;
-            for (long long off = s0; off < s1; off += RANGE_MAX) {
-                const int cnt = (int)(s1 - off < RANGE_MAX ? s1 - off : RANGE_MAX);
-                per_add_range_wg(e.tree, e.Nt, e.L, off, cnt, pmax, lds);
-                __syncthreads();                                             // this workgroup's tree stores, before it re-reads them
-            }
-        }
-        BSTAMP(2);
-        if (g.n_smp > 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // each thread: its tree stores
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&e.st->tree_ready, ticket_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        BSTAMP(3);
-    } else if (role == 2) {
-        // ---- sampler workgroup: q_agent.py:147-153 for the update that follows this launch
-        if (wg == 0) BSTAMP(4);
-        if (tid == 0)
-            while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket_val)
-                __builtin_amdgcn_s_sleep(4);
-        if (wg == 0) BSTAMP(5);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (wg == 0) BSTAMP(6);
-        const long long size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);
-        const int ntile = (g.B + 15) / 16;
-        for (int tile = wg; tile < ntile; tile += g.n_smp) {
-            presample_tile(g.smp, tile * 16, g.B, tid, size, lds, lds + 512);
-            LDS_BARRIER();                                                   // lw is rewritten by the next tile
-        }
-        if (wg == 0) BSTAMP(7);
+    if (role != 1) {
+        actor_side_role(role, wg, g, c0, nT, c1, ticket_val, lds);
     } else {
         // ---- actor workgroup
         const int D = m.D, H1 = m.H1, H2 = m.H2, A = m.A;
@@ -679,6 +770,272 @@ k_actor(NetDims m, ActorArgs g) {
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
             e.st->env_ctr = ec + (unsigned long long)g.T;
             if constexpr (NSTEP) e.st->hist_steps = hs0 + (unsigned long long)g.T;
+            e.st->fill_cnt = 0;
+            e.st->arrive = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_actor16 -- the same launch (T vector env steps, side workgroups, chunked draws) for SMALL nets (hidden sizes <= 128,
+// obs_dim <= 16, exact f32, one-step returns): 16 envs per workgroup on v_mfma_f32_16x16x4_f32. With so little weight data
+// the per-wave share of all three layers (fragment-packed shadows of dqn_net.hip: <= 2 column tiles x <= 8 k-blocks) lives in
+// registers for the whole launch, a layer is 16-128 MFMAs, and what a step costs is its fixed latency (three barriers, the
+// policy / physics lanes) -- paid once per 16 envs here instead of once per 4: BASELINE configs[2] (4 096 CartPole envs,
+// 2x64 net) has 1 024 four-env tiles but only 256 sixteen-env ones, one per CU. Same arithmetic as k_qnet_fwd (k-ordered
+// fmaf chains), hence the same actions and rows as k_actor and the CPU restatement.
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ int perm16a(int c) { return ((c & 3) << 2) | (c >> 2); }   // A-operand position of column c in its 16-block
+
+template <int KQ>                     // 16-deep k-blocks held per layer: hidden1, hidden2 <= 16*KQ; KQ/4 column tiles per wave
+__global__ void __launch_bounds__(256)
+k_actor16(NetDims m, ActorArgs g) {
+    constexpr int TN = KQ / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const EnvArgs &e = g.env;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
+    const unsigned long long nT = (unsigned long long)g.T * (unsigned long long)e.n, c1 = c0 + nT;
+    const unsigned long long ticket_val = ec + (unsigned long long)g.T;
+    const unsigned total_wgs = gridDim.x;
+    int role = 1, wg = (int)blockIdx.x - g.n_tree;
+    if ((int)blockIdx.x < g.n_tree) role = 0;
+    else if (wg >= g.G) { role = 2; wg -= g.G; }
+
+    if (role != 1) {
+        actor_side_role(role, wg, g, c0, nT, c1, ticket_val, lds);
+    } else {
+        const int D = m.D, H1 = m.H1, H2 = m.H2, A = m.A;
+        const int sx = 16 + 4, sh = 16 * KQ + 4;
+        const int DO = (D + 3) & ~3, DW = DO + 4;
+        float *lx = lds, *l1 = lx + 16 * sx, *l2 = l1 + 16 * sh, *lh = l2 + 16 * sh;
+        int *lt = reinterpret_cast<int *>(lh + 256);
+        float *ldraw = lh + 256 + 16;
+        const float *P = g.params;
+        const int c15 = lane & 15, g4 = lane >> 4;
+        const int KQ2 = H1 / 16, KQH = H2 / 16, CT1 = H1 / 16, CT2 = H2 / 16;
+
+        // this wave's share of the three layers, register-resident (clamped requests + selects: no branch around a load)
+        const f32x4 *p1 = reinterpret_cast<const f32x4 *>(g.pack + m.p_w1), *p2 = reinterpret_cast<const f32x4 *>(g.pack + m.p_w2),
+                    *ph = reinterpret_cast<const f32x4 *>(g.pack + m.p_wh);
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 w1f[TN], w2f[KQ][TN], whf[KQ];
+        float b1[TN], b2[TN], bh;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int ct = wave + 4 * t;
+            const f32x4 v = p1[(long long)(ct < CT1 ? ct : 0) * 64 + lane];          // KQ1 = 1 (obs_dim <= 16)
+            w1f[t] = ct < CT1 ? v : z4;
+            const float bv1 = P[m.o_b1 + 16 * (ct < CT1 ? ct : 0) + c15], bv2 = P[m.o_b2 + 16 * (ct < CT2 ? ct : 0) + c15];
+            b1[t] = ct < CT1 ? bv1 : 0.0f; b2[t] = ct < CT2 ? bv2 : 0.0f;
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const bool ok = ct < CT2 && kq < KQ2;
+                const f32x4 w = p2[((long long)(ok ? ct : 0) * KQ2 + (ok ? kq : 0)) * 64 + lane];
+                w2f[kq][t] = ok ? w : z4;
+            }
+        }
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) { const f32x4 w = ph[(long long)(kq < KQH ? kq : 0) * 64 + lane]; whf[kq] = kq < KQH ? w : z4; }
+        { const float bvv = P[c15 == 0 || c15 > A ? m.o_bv : m.o_ba + c15 - 1]; bh = c15 <= A ? bvv : 0.0f; }
+        float eps = e.st->epsilon;
+        const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
+        ASTAMP(0);
+
+        auto make_draws = [&](int i0, int cnt, int t0) {                     // Philox draws of steps t0 .. t0+TC-1 (waves 1..3)
+            if (wave == 0) return;
+            const int nobs = e.kind == 0 ? cnt * D : 0, per = nobs + 2 * cnt;
+            const int nst = g.T - t0 < g.TC ? g.T - t0 : g.TC;
+            for (int u = tid - 64; u < nst * per; u += 192) {
+                const int ts = u / per, v = u - ts * per;
+                const unsigned long long ecs = ec + (unsigned long long)(t0 + ts);
+                float *dw = ldraw + (ts * 16) * DW;
+                if (v < nobs) {
+                    const int il = v / D, el = v - il * D, i = i0 + il;
+                    dw[il * DW + el] = ih_normal(philox_draw(e.seed, ecs, (uint32_t)(i * (D + 1) + el), DQN_STREAM_ENV));
+                } else if (v < nobs + cnt) {
+                    const int il = v - nobs, i = i0 + il;
+                    const u32x4 o = philox_draw(e.seed, ecs, (uint32_t)i, DQN_STREAM_POLICY);   // as policy_row()
+                    dw[il * DW + DO] = u01(o.x);
+                    dw[il * DW + DO + 1] = __int_as_float((int)(((unsigned long long)o.y * (unsigned long long)A) >> 32));
+                } else if (e.kind == 0) {
+                    const int il = v - nobs - cnt, i = i0 + il;
+                    const u32x4 o = philox_draw(e.seed, ecs, (uint32_t)(i * (D + 1) + D), DQN_STREAM_ENV);
+                    const bool done = u01(o.x) < e.p_done;
+                    float rew = (((u01(o.y) + u01(o.z)) + (u01(o.w) + u01(o.x))) - 2.0f) * 1.73205078f;
+                    if (done) rew = (o.y & 1u) ? 100.0f : -100.0f;
+                    dw[il * DW + DO + 2] = done ? 1.0f : 0.0f;
+                    dw[il * DW + DO + 3] = rew;
+                }
+            }
+        };
+        for (int t = tid; t < 16 * sx + 2 * 16 * sh; t += 256) lx[t] = 0.0f;  // padding columns stay zero for the whole launch
+        // every load above is waited for here, outside the step loop
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            asm volatile("" : "+v"(w1f[t]), "+v"(b1[t]), "+v"(b2[t]));
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) asm volatile("" : "+v"(w2f[kq][t]));
+        }
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) asm volatile("" : "+v"(whf[kq]));
+        asm volatile("" : "+v"(bh), "+v"(eps));
+
+        for (int tile = wg; tile < g.tiles; tile += g.G) {
+            const int i0 = 16 * tile;
+            const int cnt = e.n - i0 < 16 ? e.n - i0 : 16;
+            LDS_BARRIER();                                                   // previous tile's LDS is dead; zero-fill done
+            {
+                const int rl = tid >> 4, c = tid & 15;
+                lx[rl * sx + perm16a(c)] = (rl < cnt && c < D) ? e.env_obs[(long long)(i0 + rl) * D + c] : 0.0f;
+            }
+            if (e.kind == 1 && tid < 16) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
+            LDS_BARRIER();
+            if (tile == wg) ASTAMP(1);
+
+            for (int t = 0; t < g.T; ++t) {
+                if (t % g.TC == 0) make_draws(i0, cnt, t);
+                const float *dstep = ldraw + ((t % g.TC) * 16) * DW;
+                const bool last = t == g.T - 1;
+                const unsigned long long ect = ec + (unsigned long long)t;
+                const long long at = a0 + (long long)t * e.n + i0;
+#pragma unroll
+                for (int tt = 0; tt < TN; ++tt) {
+                    asm volatile("" : "+v"(w1f[tt]), "+v"(b1[tt]), "+v"(b2[tt]));
+#pragma unroll
+                    for (int kq = 0; kq < KQ; ++kq) asm volatile("" : "+v"(w2f[kq][tt]));
+                }
+#pragma unroll
+                for (int kq = 0; kq < KQ; ++kq) asm volatile("" : "+v"(whf[kq]));
+                asm volatile("" : "+v"(bh), "+v"(eps));
+                // layer 1: h1 = relu(x @ w1 + b1)                              dddqn.py:25-26
+                {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(lx + c15 * sx + 4 * g4);
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = MFMA4(a4.x, w1f[tt][0], acc); acc = MFMA4(a4.y, w1f[tt][1], acc);
+                        acc = MFMA4(a4.z, w1f[tt][2], acc); acc = MFMA4(a4.w, w1f[tt][3], acc);
+                        const int ct = wave + 4 * tt;
+                        if (ct < CT1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float v = acc[r] + b1[tt]; l1[(4 * g4 + r) * sh + 16 * ct + perm16a(c15)] = v > 0.0f ? v : 0.0f; }
+                        }
+                    }
+                }
+                LDS_BARRIER();
+                if (tile == wg) ASTAMP(2 + 4 * t);
+                // layer 2: h2 = relu(h1 @ w2 + b2)                             dddqn.py:27-28
+                {
+                    f32x4 acc[TN];
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float *ar = l1 + c15 * sh + 4 * g4;
+#pragma unroll
+                    for (int kq = 0; kq < KQ; ++kq) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(ar + 16 * kq);
+#pragma unroll
+                        for (int tt = 0; tt < TN; ++tt) {
+                            acc[tt] = MFMA4(a4.x, w2f[kq][tt][0], acc[tt]); acc[tt] = MFMA4(a4.y, w2f[kq][tt][1], acc[tt]);
+                            acc[tt] = MFMA4(a4.z, w2f[kq][tt][2], acc[tt]); acc[tt] = MFMA4(a4.w, w2f[kq][tt][3], acc[tt]);
+                        }
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < TN; ++tt) {
+                        const int ct = wave + 4 * tt;
+                        if (ct < CT2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float v = acc[tt][r] + b2[tt]; l2[(4 * g4 + r) * sh + 16 * ct + perm16a(c15)] = v > 0.0f ? v : 0.0f; }
+                        }
+                    }
+                }
+                LDS_BARRIER();
+                if (tile == wg) ASTAMP(3 + 4 * t);
+                if (wave == 0) {
+                    // heads: column 0 = val (dddqn.py:29), columns 1..A = adv (:30); then dueling combine + policy per env
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *ar = l2 + c15 * sh + 4 * g4;
+#pragma unroll
+                    for (int kq = 0; kq < KQ; ++kq) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(ar + 16 * kq);
+                        acc = MFMA4(a4.x, whf[kq][0], acc); acc = MFMA4(a4.y, whf[kq][1], acc);
+                        acc = MFMA4(a4.z, whf[kq][2], acc); acc = MFMA4(a4.w, whf[kq][3], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lh[(4 * g4 + r) * 16 + c15] = acc[r] + bh;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order
+                    if (lane < cnt) {
+                        const int il = lane, i = i0 + il;
+                        const float4 *hrow = reinterpret_cast<const float4 *>(lh + il * 16);
+                        const float4 h0 = hrow[0], h1 = hrow[1], h2 = hrow[2], h3 = hrow[3];
+                        const float4 dr = *reinterpret_cast<const float4 *>(dstep + il * DW + DO);   // u, random action, done, reward
+                        const float h[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < 15; ++a) if (a < A) sum = sum + h[1 + a];
+                        const float mean = __fdiv_rn(sum, (float)A);                 // dddqn.py:31
+                        int act = 0;
+                        float best = (h[0] + h[1]) - mean;
+#pragma unroll
+                        for (int a = 1; a < 15; ++a) {
+                            const float qa = (h[0] + h[1 + a]) - mean;
+                            if (a < A && qa > best) { best = qa; act = a; }          // first max wins (compute_action :70)
+                        }
+                        if (!(eps < dr.x)) act = __float_as_int(dr.y);               // q_agent.py:137-141
+                        if (last) g.act_out[i] = act;
+                        long long k = at + il; if (k >= e.cap) k -= e.cap;
+                        if (e.kind == 1) {
+                            float sv[4];
+                            for (int j = 0; j < 4; ++j) { sv[j] = lx[il * sx + perm16a(j)]; e.states[k * 4 + j] = sv[j]; }
+                            const bool term = cartpole_step(sv, act);
+                            const int tt = lt[il] + 1;
+                            const bool done = term || tt >= e.max_steps;             // q_agent.py:179-180
+                            for (int j = 0; j < 4; ++j) e.observations[k * 4 + j] = sv[j];
+                            e.actions[k] = act; e.rewards[k] = term ? e.term_reward : 1.0f; e.dones[k] = done ? 1 : 0;
+                            if (done) {
+                                atomicAdd(&e.st->ep_count, 1ull);
+                                atomicAdd(&e.st->ep_steps, (unsigned long long)tt);
+                                const u32x4 o = philox_draw(e.seed, ect, (uint32_t)i, DQN_STREAM_ENV);
+                                sv[0] = (u01(o.x) * 0.1f) - 0.05f; sv[1] = (u01(o.y) * 0.1f) - 0.05f;
+                                sv[2] = (u01(o.z) * 0.1f) - 0.05f; sv[3] = (u01(o.w) * 0.1f) - 0.05f;
+                            }
+                            lt[il] = done ? 0 : tt;
+                            for (int j = 0; j < 4; ++j) lx[il * sx + perm16a(j)] = sv[j];
+                            if (last) {
+                                e.env_t[i] = done ? 0 : tt;
+                                for (int j = 0; j < 4; ++j) e.env_obs[(long long)i * 4 + j] = sv[j];
+                            }
+                        } else {
+                            e.actions[k] = act;                                      // replay_buffer.py:60
+                            e.rewards[k] = dr.w;                                     // :61
+                            e.dones[k] = dr.z != 0.0f ? 1 : 0;                       // :63
+                        }
+                    }
+                } else if (e.kind == 0) {
+                    // waves 1..3, meanwhile: the synthetic transition of the step out of the draw buffer
+                    for (int u = tid - 64; u < cnt * D; u += 192) {
+                        const int il = u / D, el = u - il * D, i = i0 + il;
+                        long long k = at + il; if (k >= e.cap) k -= e.cap;
+                        const float nx = dstep[il * DW + el];
+                        e.states[k * D + el] = lx[il * sx + perm16a(el)];            // replay_buffer.py:59
+                        e.observations[k * D + el] = nx;                             // :62
+                        lx[il * sx + perm16a(el)] = nx;                              // q_agent.py:183 (read by this thread only)
+                        if (last) e.env_obs[(long long)i * D + el] = nx;
+                    }
+                }
+                LDS_BARRIER();
+                if (tile == wg) { ASTAMP(4 + 4 * t); ASTAMP(5 + 4 * t); }
+            }
+        }
+    }
+    LDS_BARRIER();
+    if (tid == 0) {
+        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
+        if (ticket == total_wgs - 1u) {
+            e.st->ring_counter = c1;                                                              // replay_buffer.py:64
+            e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
+            e.st->env_ctr = ec + (unsigned long long)g.T;
+            e.st->fill_cnt = 0;
             e.st->arrive = 0;
         }
     }
@@ -690,15 +1047,54 @@ bool actor_multi_supported(const NetDims &m, int n_envs, int T) {
     return T >= 1 && m.H1 <= 256 && m.H2 <= 256 && m.D <= 256;
 }
 
+// sampler workgroups of an actor launch: one per 16 NR batch rows, at most `cap`; NR (rows per lane group, in flight
+// together) doubles up to 4 before a workgroup has to loop over tiles
+static void set_samplers(ActorArgs &g, int B, int cap) {
+    g.NR = 1; g.n_smp = 0;
+    if (B <= 0) return;
+    if (cap > 254) cap = 254;
+    while (g.NR < 4 && (B + 16 * g.NR - 1) / (16 * g.NR) > cap) g.NR *= 2;
+    g.n_smp = (B + 16 * g.NR - 1) / (16 * g.NR);
+    if (g.n_smp > cap) g.n_smp = cap;
+}
+
 void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
                         int32_t *act_out, int B, const SampleArgs *smp, bool bf16) {
     ActorArgs g{};
     g.env = env; g.T = T; g.params = params; g.pack = pack; g.act_out = act_out;
+    // small nets (exact f32, one-step returns): 16 envs per workgroup on the 16x16x4 MFMA, all weights in registers (k_actor16)
+    const bool wide = !bf16 && env.n_step <= 1 && m.D <= 16 && m.H1 <= 128 && m.H2 <= 128 && getenv("DQN_NO_ACTOR16") == nullptr;
+    if (wide) {
+        // (about 110-180 registers per thread and <= 70 KB of LDS: two workgroups of this kernel share a CU, so up to 510 are
+        // resident at once -- room for one sampler workgroup per 16 batch rows up to 255 beside the actors)
+        g.n_tree = env.tree ? 1 : 0;
+        g.tiles = (env.n + 15) / 16;
+        set_samplers(g, (smp && env.tree && B > 0) ? B : 0, g.tiles <= 255 ? 509 - g.tiles : 254);
+        const int room = 2 * 255 - g.n_tree - g.n_smp;
+        g.G = g.tiles < room ? g.tiles : room;
+        g.B = B;
+        if (g.n_smp) g.smp = *smp;
+        const int KQ = (m.H1 <= 64 && m.H2 <= 64) ? 4 : 8;
+        const int DWh = ((m.D + 3) & ~3) + 4;
+        g.TC = 6144 / (16 * DWh);
+        if (g.TC > T) g.TC = T;
+        if (g.TC < 1) g.TC = 1;
+        size_t lds = sizeof(float) * (16 * 20 + 2 * 16 * (size_t)(16 * KQ + 4) + 256 + 16 + (size_t)g.TC * 16 * DWh);
+        if (g.n_tree) {
+            size_t need = sizeof(float) * 64;
+            if (lds < need) lds = need;
+            if (env.rebuild_top) { need = sizeof(float) * (env.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << env.L); if (lds < need) lds = need; }
+        }
+        if (g.n_smp && lds < sizeof(float) * (2048 + 64)) lds = sizeof(float) * (2048 + 64);
+        const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
+        if (KQ == 4) DQN_LAUNCH((k_actor16<4>), grid, block, lds, s, m, g);
+        else DQN_LAUNCH((k_actor16<8>), grid, block, lds, s, m, g);
+        return;
+    }
     // the register-resident weight slab limits a CU to ONE workgroup of this kernel, whatever its role: keep the
     // grid within the 256 CUs so that tree, sampler and actor workgroups all run side by side
     g.n_tree = env.tree ? 1 : 0;
-    g.n_smp = (smp && env.tree && B > 0) ? (B + 15) / 16 : 0;
-    if (g.n_smp > 64) g.n_smp = 64;
+    set_samplers(g, (smp && env.tree && B > 0) ? B : 0, 64);
     g.tiles = (env.n + 3) / 4;
     const int room = 255 - g.n_tree - g.n_smp;
     g.G = g.tiles < room ? g.tiles : room;
@@ -716,12 +1112,11 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     lds += sizeof(float) * (size_t)g.TC * 4 * DWh;
     if (bf16) lds += 2 * (4 * (size_t)(16 * KB + 8) + (size_t)(m.A + 5) * (16 * KB2 + 8));
     if (g.n_tree) {
-        const size_t nT = (size_t)T * (size_t)env.n;
-        size_t need = sizeof(float) * (2 * ((nT <= RANGE_MAX ? nT : RANGE_MAX) + 2) + 64);
+        size_t need = sizeof(float) * 64;
         if (lds < need) lds = need;
         if (env.rebuild_top) { need = sizeof(float) * (env.L >= PW_TOP ? (size_t)256 * 68 : (size_t)1 << env.L); if (lds < need) lds = need; }
     }
-    if (g.n_smp && lds < sizeof(float) * 528) lds = sizeof(float) * 528;
+    if (g.n_smp && lds < sizeof(float) * (2048 + 64)) lds = sizeof(float) * (2048 + 64);
     const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
 #define ACTOR_CASE(K1, K2) if (KB == K1 && KB2 == K2) {                                                     \
         if (bf16) { if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true, true>), grid, block, lds, s, m, g);    \

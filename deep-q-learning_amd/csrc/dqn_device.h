@@ -32,8 +32,11 @@ struct DqnState {
     unsigned long long ep_count;       // finished episodes of the device-resident envs (CartPole)
     unsigned long long ep_steps;       // env steps (= return, reward 1 per step) summed over finished episodes
     unsigned long long hist_steps;     // vector env steps filed in the n-step history since dqn_env_reset
-    unsigned long long tree_ready;     // env step counter up to which the leaves are in the tree: released by the tree
-                                       // workgroup of an actor launch, awaited by its sampler workgroups (dqn_actor.hip)
+    // cross-workgroup hand-overs of an actor launch, each on its own 128-B line (hundreds of workgroups poll / bump them):
+    alignas(128) unsigned long long tree_ready;   // env step counter up to which the leaves are in the tree: released by the
+                                       // tree workgroup, awaited by the sampler workgroups (dqn_actor.hip)
+    alignas(128) unsigned int fill_cnt;           // sampler workgroups that have stored their share of the new leaves' inner
+                                       // nodes (reset by the launch's commit)
 };
 
 enum { DQN_STREAM_PER = 0, DQN_STREAM_UNIFORM = 1, DQN_STREAM_POLICY = 2, DQN_STREAM_ENV = 3 };

@@ -117,7 +117,7 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
 
 // ------------------------------------------------------------ synthetic env + leaf-range insert
 // Shared by k_per_add (dqn_replay.hip) and k_actor (dqn_actor.hip), whose tree workgroup inserts the new leaves.
-#define RANGE_MAX 4096
+#define RANGE_MAX (1 << 30)       // the range insert takes any n (kept for its callers' piece loops)
 
 struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic envs; st == NULL => not an actor launch
     DqnState *st;
@@ -190,76 +190,90 @@ __device__ __forceinline__ void per_add_slow(float *tree, long long Nt, int L, u
     }
 }
 
-// Leaf-range insert: new transitions occupy CONSECUTIVE leaves [a, a+n) at priority pmax, so the touched nodes
-// of every level are one contiguous range whose children are either in the previous level's range or one
-// untouched boundary sibling on each side (prefetched from HBM up front, all levels at once). Wide levels run
-// out of LDS with LDS-only barriers; once a level fits one wave it continues in registers (children by lane
-// shuffle); the last <= 2-node levels are wave-uniform scalar arithmetic. parent = left + right throughout.
-// Whole workgroup; lds: 2*(n+2) + 64 floats; requires n <= RANGE_MAX and a + n <= ring capacity.
-__device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int L, long long a, int n, float pmax, float *lds) {
+// Leaf-range insert: new transitions occupy CONSECUTIVE leaves [a, a+n), all at the running max priority pmax. At level l
+// the touched nodes are the contiguous range [first>>l, last>>l]; every node strictly inside that range has its whole
+// subtree inside [a, a+n), so its value is pmax * 2^l -- exactly what summing two equal children level by level gives
+// (x + x is exact), no dependency on the level below. Only the two END nodes of each level are real sums: of an inner or
+// end child and, possibly, one untouched sibling outside the range. So: the outside siblings of all levels are
+// requested up front (L1-bypassing: an earlier piece of the same insert, or the tree-top rebuild, run by this workgroup,
+// may have written them after this CU cached their lines); all inner nodes of all levels are plain parallel stores;
+// one wave walks the <= 2 end nodes per level up to the root in registers. Any n, no LDS image of the range.
+// Whole workgroup; lds: 64 floats; requires a + n <= ring capacity.
+// Tree stores that another workgroup of the SAME launch reads (actor launch: tree workgroup / fillers -> samplers):
+// device-coherent write-through stores (sc1). Once the issuing wave's vmcnt has drained they are visible to every XCD,
+// so the hand-over needs no release fence -- a fence writes back the XCD's WHOLE dirty L2 (18 us beside 16 384 fresh
+// ring rows). Plain kernels that use these helpers lose nothing: the data had to reach HBM anyway.
+__device__ __forceinline__ void tree_st(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tree_st4(float4 *p, const float4 &v) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+}
+
+// inner nodes of levels 0 .. lmax of the leaf range [a, a+n): share `w` of `nw` (whole workgroups; w = 0 also stores the
+// few unaligned nodes at the ends of each level's run). 16-B stores for the aligned middle.
+__device__ __forceinline__ void per_add_range_fill(float *tree, long long Nt, int lmax, long long a, int n, float pmax, int w, int nw) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    float *v0 = lds, *v1 = v0 + n + 2, *bl = v1 + n + 2, *br = bl + 32;
+    const long long first = Nt + a, last = Nt + a + n - 1;
+    for (int l = 0; l <= lmax; ++l) {
+        const long long lo = first >> l, hi = last >> l;
+        if (hi - lo < 2) break;                                          // (runs only shrink going up)
+        const float v = pmax * (float)(1u << l);
+        const long long p0 = lo + 1, p1 = hi;                            // [p0, p1)
+        const long long q0 = (p0 + 3) & ~3ll, q1 = p1 & ~3ll;
+        if (q0 < q1) {
+            if (w == 0) {
+                for (long long p = p0 + tid; p < q0; p += nt) tree_st(tree + p, v);
+                for (long long p = q1 + tid; p < p1; p += nt) tree_st(tree + p, v);
+            }
+            float4 *t4 = reinterpret_cast<float4 *>(tree);
+            const float4 v4 = {v, v, v, v};
+            for (long long q = (q0 >> 2) + (long long)w * nt + tid; q < (q1 >> 2); q += (long long)nw * nt) tree_st4(t4 + q, v4);
+        } else if (w == 0) {
+            for (long long p = p0 + tid; p < p1; p += nt) tree_st(tree + p, v);
+        }
+    }
+}
+
+// the two END nodes of levels 0 .. lmax (+ the parents they feed at level lmax + 1 when lmax < L - 1 is NOT wanted: the walk
+// stops after writing level lmax). One thread; outside siblings requested up front by the whole workgroup. lds: 64 floats.
+__device__ __forceinline__ void per_add_range_ends(float *tree, long long Nt, int L, int lmax, long long a, int n, float pmax, float *lds) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float *bl = lds, *br = lds + 32;
     const long long first = Nt + a, last = Nt + a + n - 1;
     for (int l = tid; l < L; l += nt) {
         const long long lo = first >> l, hi = last >> l;
-        // (L1-bypassing loads: a previous piece of the same insert, run by this workgroup, may have written these nodes
-        // after this CU's L1 cached their lines)
         bl[l] = (lo & 1) ? __hip_atomic_load(&tree[lo - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
         br[l] = (hi & 1) ? 0.0f : __hip_atomic_load(&tree[hi + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int j = tid; j < n; j += nt) { v0[j] = pmax; tree[first + j] = pmax; }
-    LDS_BARRIER();
-    float *cur = v0, *nxt = v1;
-    int l = 0;
-    for (; l < L; ++l) {
-        const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-        const int cnt = (int)(phi - plo + 1);
-        if (hi - lo + 1 <= 64) break;
-        for (int j = tid; j < cnt; j += nt) {
-            const long long p = plo + j;
-            const float lv = (2 * p >= lo) ? cur[2 * p - lo] : bl[l];
-            const float rv = (2 * p + 1 <= hi) ? cur[2 * p + 1 - lo] : br[l];
-            const float v = lv + rv;
-            nxt[j] = v;
-            tree[p] = v;
-        }
-        LDS_BARRIER();
-        float *t = cur; cur = nxt; nxt = t;
-    }
-    if (tid < 64) {
-        const long long lo0 = first >> l, hi0 = last >> l;
-        float valr = (l < L && tid <= hi0 - lo0) ? cur[tid] : 0.0f;
-        const int blr = __float_as_int(tid < L ? bl[tid] : 0.0f), brr = __float_as_int(tid < L ? br[tid] : 0.0f);
-        for (; l < L; ++l) {
-            const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-            if (hi - lo + 1 <= 2) break;
-            const int cnt = (int)(phi - plo + 1);
-            const long long p = plo + tid;
-            const int li = (int)(2 * p - lo), ri = li + 1;
-            float lv = __shfl(valr, li & 63, 64), rv = __shfl(valr, ri & 63, 64);
-            const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
-            const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
-            if (li < 0) lv = blv;
-            if (2 * p + 1 > hi) rv = brv;
-            const float v = lv + rv;
-            if (tid < cnt) tree[p] = v;
-            valr = v;
-        }
-        float n0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 0));
-        float n1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(valr), 1));
-        for (; l < L; ++l) {
-            const long long lo = first >> l, hi = last >> l, plo = lo >> 1, phi = hi >> 1;
-            const float blv = __int_as_float(__builtin_amdgcn_readlane(blr, l));
-            const float brv = __int_as_float(__builtin_amdgcn_readlane(brr, l));
-            const float c_lo_l = (2 * plo >= lo) ? n0 : blv;
-            const float c_lo_r = (2 * plo + 1 <= hi) ? ((2 * plo + 1 == lo) ? n0 : n1) : brv;
-            const float p0 = c_lo_l + c_lo_r;
-            float p1 = 0.0f;
-            if (phi != plo) p1 = n1 + ((2 * phi + 1 <= hi) ? n1 : brv);      // 2*phi == hi here (value n1)
-            if (tid == 0) { tree[plo] = p0; if (phi != plo) tree[phi] = p1; }
-            n0 = p0; n1 = p1;
+    LDS_BARRIER();                                                       // bl / br are in LDS
+    if (tid == 0) {
+        float vlo = pmax, vhi = pmax;                                    // values of the end nodes; inner neighbours in closed form
+        long long lo = first, hi = last;
+        tree_st(tree + lo, vlo); tree_st(tree + hi, vhi);
+        for (int l = 0; l < lmax; ++l) {
+            const float inner = pmax * (float)(1u << l);                 // value of a node strictly inside [lo, hi] at level l
+            const long long plo = lo >> 1, phi = hi >> 1;
+            float nlo;
+            if (lo & 1) nlo = bl[l] + vlo;                               // left sibling is outside the range
+            else nlo = vlo + (lo + 1 > hi ? br[l] : (lo + 1 == hi ? vhi : inner));
+            float nhi = nlo;
+            if (phi != plo) {
+                if (hi & 1) nhi = (hi - 1 == lo ? vlo : inner) + vhi;     // hi - 1 >= lo here (different parents)
+                else nhi = vhi + br[l];                                  // right sibling is outside the range
+            }
+            lo = plo; hi = phi; vlo = nlo; vhi = nhi;
+            tree_st(tree + lo, vlo);
+            if (hi != lo) tree_st(tree + hi, vhi);
         }
     }
+    LDS_BARRIER();                                                       // bl / br may be reused by the next segment
+}
+
+// the whole insert by one workgroup (API path k_per_add; actor launches without sampler workgroups)
+__device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int L, long long a, int n, float pmax, float *lds) {
+    per_add_range_fill(tree, Nt, L, a, n, pmax, 0, 1);
+    per_add_range_ends(tree, Nt, L, L, a, n, pmax, lds);
 }
 
 // dense top of the tree, whole workgroup: depth TOP-1 from the depth-TOP pairs in HBM, the levels above out of an
@@ -314,7 +328,7 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
             const float4 *img = reinterpret_cast<const float4 *>(top + 256);
             float4 *out = reinterpret_cast<float4 *>(tree + 256);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { const int q = u * 256 + tid; if (q < (16384 - 256) / 4) out[q] = img[q]; }
+            for (int u = 0; u < 16; ++u) { const int q = u * 256 + tid; if (q < (16384 - 256) / 4) tree_st4(out + q, img[q]); }
         }
         STAMP(2, 3);
         for (int d = 7; d >= 0; --d) {
@@ -323,7 +337,7 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
                 const int p = cnt + tid;
                 const float s = top[2 * p] + top[2 * p + 1];
                 top[p] = s;
-                tree[p] = s;
+                tree_st(tree + p, s);
             }
             LDS_BARRIER();
         }
@@ -337,7 +351,7 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
         const float2 c = *reinterpret_cast<const float2 *>(tree + 2 * (h + j));
         const float v = c.x + c.y;
         top[h + j] = v;
-        tree[h + j] = v;
+        tree_st(tree + h + j, v);
     }
     __syncthreads();
     for (int d = TOP - 2; d >= 0; --d) {
@@ -346,7 +360,7 @@ __device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
             const int p = cnt + j;
             const float v = top[2 * p] + top[2 * p + 1];
             top[p] = v;
-            tree[p] = v;
+            tree_st(tree + p, v);
         }
         LDS_BARRIER();
     }

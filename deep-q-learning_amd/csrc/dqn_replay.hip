@@ -511,7 +511,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 static inline int pow2_threads(int n, int lo, int hi) { int t = lo; while (t < n && t < hi) t <<= 1; return t; }
 
 void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap) {
-    const size_t lds = (n <= RANGE_MAX) ? sizeof(float) * (2 * (size_t)(n + 2) + 64) : 0;
+    const size_t lds = sizeof(float) * 64;
     hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, st, tree, Nt, L, n, cap);
 }
 

@@ -25,17 +25,22 @@ NAMES = {0: ("k_qnet_fwd (+ fused row backward)", ["start", "x staged", "L1 done
              [f"t{t} {w}" for t in range(4) for w in ("L1 done", "L2 done", "heads+policy done", "env done")]),
          2: ("per_top_wg (tree workgroup of k_actor)", ["start", "depth-14 loads landed, depth 13 summed", "register tree written to the LDS image", "coalesced copy-out issued", "LDS levels done", "final drain"]),
          3: ("k_actor side chain (tree workgroup, then sampler workgroup 0)",
-             ["tree wg start", "top rebuilt", "leaves inserted", "flag released", "sampler start", "flag seen", "acquired", "batch drawn"])}
+             ["tree wg start", "end nodes walked", "inner nodes in + top rebuilt", "flag released", "sampler start", "flag seen", "acquired", "batch drawn",
+              "tile 0: u drawn", "levels 1-4", "levels 5-8", "levels 9-12", "levels 13-16", "levels 17-20", "leaf, weight, stores", "barrier"])}
 
 
 def main():
+    if os.environ.get("DQN_STAMPS_CFG3") == "1":           # BASELINE configs[2]: CartPole, 4096 envs, 2x64, B = 8192
+        bench.D, bench.H1, bench.H2, bench.A, bench.B, bench.N_ENVS = 4, 64, 64, 2, 8192, 4096
     eng = dq.Engine(dq.EngineConfig(obs_dim=bench.D, hidden1=bench.H1, hidden2=bench.H2, num_actions=bench.A,
                                     capacity=1 << bench.LOG2N, use_per=True, max_batch=bench.B, seed=1,
                                     precision=os.environ.get("DQN_STAMPS_PRECISION", "f32")))
     gen = torch.Generator(device=eng.device); gen.manual_seed(0)
     eng.set_params(torch.randn(eng.param_count) * 0.05); eng.sync_target()
     bench.prefill(eng, gen)
-    eng.env_reset(torch.randn(bench.N_ENVS, bench.D, device=eng.device, generator=gen), 0.01)
+    if os.environ.get("DQN_STAMPS_CFG3") == "1":
+        eng.env_config("cartpole", 500, -1.0)
+    eng.env_reset(torch.randn(bench.N_ENVS, bench.D, device=eng.device, generator=gen) * 0.05, 0.01)
     eng.set_epsilon(0.15)
     with torch.cuda.stream(eng.stream):
         for _ in range(100):
@@ -59,6 +64,9 @@ def main():
     if st[0, 11, 0]:
         print("k_qnet_fwd layer-1 phase (cycles since x staged): " + ", ".join(
             f"{lab} +{int(st[0, i, 0] - st[0, 1, 0])}" for lab, i in (("MFMAs done", 11), ("epilogue stores issued", 12), ("head weights requested", 13), ("barrier passed", 2))))
+    if st[2, 6, 0]:
+        print("per_add_range_wg (cycles since its start): " + ", ".join(
+            f"{lab} +{int(st[2, i, 0] - st[2, 6, 0])}" for lab, i in (("inner nodes stored", 7), ("barrier", 8), ("end-node chain done", 9))))
     for k, (name, labels) in NAMES.items():
         t = st[k, :len(labels)]
         cyc = t[:, 0] - t[0, 0]; real = (t[:, 1] - t[0, 1]) * 10.0     # ns
