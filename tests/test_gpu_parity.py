@@ -630,6 +630,49 @@ def test_cfg3_full_size_loop(dq):
     e.close()
 
 
+@pytest.mark.parametrize("n,T,L_,B", [(4000, 4, 15, 4096), (1000, 3, 14, 2048)])
+def test_wrapping_leaf_insert_spread_over_sampler_workgroups(dq, n, T, L_, B):
+    """The actor launch's insert of n*T new leaves when the ring WRAPS inside the launch (two leaf segments), with the
+    inner nodes stored by sampler workgroups and the end nodes walked by the tree workgroup (dqn_actor.hip,
+    actor_side_role), and 2 batch rows per sampler lane group (B / 16 exceeds the sampler workgroups available):
+    3 iterations of (T vector env steps + 1 update) vs the oracle, whole-tree invariant, sorted in-range batch."""
+    import torch
+    dims = CFGS["cfg3"]
+    D = dims[0]
+    N = 1 << L_
+    fill = N - n * T // 3                                                # the first launch already wraps
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=31, lr=1e-3)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, fill, 32, terminal_frac=0.05)
+    r = np.clip(r, -2, 2)
+    for k in range(0, fill, 4096):
+        sl = slice(k, min(k + 4096, fill))
+        ct.add(cr.add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)); e.replay_add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)
+    P0 = rand_params(dims, 33)
+    e.set_params(P0); e.sync_target()
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 31, beta=0.4)
+    obs = np.random.default_rng(34).standard_normal((n, D)).astype(np.float32)
+    e.env_reset(obs, p_done=0.02); e.set_epsilon(0.1)
+    ctr = 0
+    for _ in range(3):
+        for _ in range(T):
+            ctr = lrn.actor_step(obs, 0.1, 0.02, ctr)
+        lrn.update(B)
+    with torch.cuda.stream(e.stream):
+        e.train_iters(3, T, B)
+        e.stream.synchronize()
+    assert e.replay_size() == (cr.size, cr.rb.counter) and e.opt_count() == 3
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
+    assert np.array_equal(host(e.buffer(dq._lib.BUF_STATES).view(N, D)), cr.arrays()[0])
+    t = host(e.buffer(dq._lib.BUF_TREE))
+    k = np.arange(1, N)
+    assert np.array_equal(t[k], t[2 * k] + t[2 * k + 1])                 # every parent = left + right, whole tree
+    assert np.allclose(t, ct.tree, rtol=1e-4, atol=1e-6)
+    idx = host(e.buffer(dq._lib.BUF_BATCH_IDX, torch.int32))[:B]
+    assert np.all(np.diff(idx) >= 0) and idx.max() < cr.size
+    e.close()
+
+
 def test_tree_invariant_under_replay_stress(dq):
     """400 graph-replayed updates + 1600 vector env steps at the bench configuration (write-back waves riding in the dW
     launch, top rebuilt by k_per_top, leaf-range inserts by the actor launches): `parent = left + right` must hold for

@@ -17,14 +17,20 @@ import deep_q_learning_amd as dq  # noqa: E402
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=40.0); args = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=40.0)
+    ap.add_argument("--cfg3", action="store_true", help="BASELINE configs[2] (CartPole, 4096 envs, 2x64, B = 8192) instead of the bench shape")
+    args = ap.parse_args()
+    if args.cfg3:
+        bench.D, bench.H1, bench.H2, bench.A, bench.B, bench.N_ENVS = 4, 64, 64, 2, 8192, 4096
     for prec in ("f32", "bf16"):
         e = dq.Engine(dq.EngineConfig(obs_dim=bench.D, hidden1=bench.H1, hidden2=bench.H2, num_actions=bench.A, capacity=1 << bench.LOG2N,
                                       use_per=True, max_batch=bench.B, seed=7, precision=prec))
         gen = torch.Generator(device=e.device); gen.manual_seed(0)
         e.set_params(bench.init_params(e.param_count)); e.sync_target()
         bench.prefill(e, gen)
-        e.env_reset(torch.randn(bench.N_ENVS, bench.D, device=e.device, generator=gen), 0.01); e.set_epsilon(0.15)
+        if args.cfg3:
+            e.env_config("cartpole", 500, -1.0)
+        e.env_reset(torch.randn(bench.N_ENVS, bench.D, device=e.device, generator=gen) * (0.05 if args.cfg3 else 1.0), 0.01); e.set_epsilon(0.15)
         N = 1 << bench.LOG2N
         k = torch.arange(1, N, device=e.device)
         t0 = time.time(); iters = 0; checks = 0
