@@ -287,6 +287,18 @@ def main():
         flag = torch.tensor([ok], device=eng.device, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         native = bool(flag.item())
+        if native:                                            # the captured form once, guarded: a capture / instantiate failure
+            ok = 1                                            # (same software on every rank => on every rank) also falls back
+            try:
+                with torch.cuda.stream(st):
+                    eng.train_iters(ITERS_PER_GRAPH, TRAIN_FREQ, B, st)
+                torch.cuda.synchronize()
+            except Exception as ex:                           # noqa: BLE001
+                print(f"[bench] captured all-reduce unavailable on rank {rank}: {ex}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device=eng.device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
 
     def run_steps(k):
         """exactly k steps; a step = TRAIN_FREQ vector env steps + one update"""
