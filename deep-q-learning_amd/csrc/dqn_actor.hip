@@ -278,6 +278,24 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
     }
 }
 
+// `s_waitcnt vmcnt(VM)` whose operands are CNT registers of the slab (AG: accumulation VGPRs): nothing that reads them can be
+// scheduled ahead of the wait. Vector-memory results return in request order, so "at most VM outstanding" = "everything
+// but the youngest VM requests has landed" (younger requests of any kind only make the wait more conservative).
+template <int CNT, bool AG, int VM>
+__device__ __forceinline__ void wait_tied(f32x4 *w) {
+    static_assert(CNT == 16 || CNT == 8 || CNT == 4, "segment sizes of the W2 slab");
+    if constexpr (CNT == 16) {
+        if constexpr (AG) asm volatile("s_waitcnt vmcnt(%[n])" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]), "+a"(w[4]), "+a"(w[5]), "+a"(w[6]), "+a"(w[7]), "+a"(w[8]), "+a"(w[9]), "+a"(w[10]), "+a"(w[11]), "+a"(w[12]), "+a"(w[13]), "+a"(w[14]), "+a"(w[15]) : [n] "n"(VM) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]) : [n] "n"(VM) : "memory");
+    } else if constexpr (CNT == 8) {
+        if constexpr (AG) asm volatile("s_waitcnt vmcnt(%[n])" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]), "+a"(w[4]), "+a"(w[5]), "+a"(w[6]), "+a"(w[7]) : [n] "n"(VM) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : [n] "n"(VM) : "memory");
+    } else {
+        if constexpr (AG) asm volatile("s_waitcnt vmcnt(%[n])" : "+a"(w[0]), "+a"(w[1]), "+a"(w[2]), "+a"(w[3]) : [n] "n"(VM) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : [n] "n"(VM) : "memory");
+    }
+}
+
 // KB = 16-row k-blocks of the register-resident W2 slab: hidden1 <= 16*KB (columns / rows past hidden1 are zeros, and
 // x*0 + acc leaves every chain unchanged), so the layer-2 chain is straight-line code for each size class
 // KB2: the same for hidden2 (the heads' chains run over 16*KB2 zero-padded k).
@@ -542,7 +560,10 @@ k_actor(NetDims m, ActorArgs g) {
                     }
                 }
                 if (!w2_landed) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); w2_landed = true; ASTAMP(24);
+                    // bf16 mode converts the whole slab once: wait for all of it. Exact mode: the layer-2 chain below waits
+                    // for the slab quarter by quarter, so the first step's chain runs while the rest is still arriving.
+                    if constexpr (BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    w2_landed = true; ASTAMP(24);
                     if constexpr (BF) {
 #pragma unroll
                         for (int kq = 0; kq < 4 * KB; ++kq) {
@@ -593,6 +614,19 @@ k_actor(NetDims m, ActorArgs g) {
                     for (int q = 0; q < 4; ++q) ab[q] = *reinterpret_cast<const float4 *>(ar + 4 * q);
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) {
+                        // (after the first step these waits find nothing of the slab outstanding)
+                        if constexpr (KB >= 4) {
+                            constexpr int SEG = KB;                             // 4 KB / 4 float4 registers per quarter
+                            if (kb % (KB / 4) == 0) {
+                                const int sg = kb / (KB / 4);
+                                if (sg == 0) wait_tied<SEG, false, 3 * SEG>(w2q);
+                                else if (sg == 1) wait_tied<SEG, (SEG >= 16), 2 * SEG>(w2q + SEG);
+                                else if (sg == 2) wait_tied<SEG, (2 * SEG >= 16), SEG>(w2q + 2 * SEG);
+                                else wait_tied<SEG, (3 * SEG >= 16), 0>(w2q + 3 * SEG);
+                            }
+                        } else if (kb == 0) {
+                            if constexpr (KB == 2) wait_tied<8, false, 0>(w2q); else wait_tied<4, false, 0>(w2q);
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const float4 a4 = ab[u];
