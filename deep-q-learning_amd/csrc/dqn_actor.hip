@@ -1017,15 +1017,27 @@ k_actor16(NetDims m, ActorArgs g) {
                         const float4 dr = *reinterpret_cast<const float4 *>(dstep + il * DW + DO);   // u, random action, done, reward
                         const float h[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
                         float sum = 0.0f;
-#pragma unroll
-                        for (int a = 0; a < 15; ++a) if (a < A) sum = sum + h[1 + a];
-                        const float mean = __fdiv_rn(sum, (float)A);                 // dddqn.py:31
                         int act = 0;
-                        float best = (h[0] + h[1]) - mean;
+                        if (A <= 4) {                  // (uniform branch: the usual case without the general one's 15 select-guarded links)
 #pragma unroll
-                        for (int a = 1; a < 15; ++a) {
-                            const float qa = (h[0] + h[1 + a]) - mean;
-                            if (a < A && qa > best) { best = qa; act = a; }          // first max wins (compute_action :70)
+                            for (int a = 0; a < 4; ++a) if (a < A) sum = sum + h[1 + a];
+                            const float mean = __fdiv_rn(sum, (float)A);             // dddqn.py:31
+                            float best = (h[0] + h[1]) - mean;
+#pragma unroll
+                            for (int a = 1; a < 4; ++a) {
+                                const float qa = (h[0] + h[1 + a]) - mean;
+                                if (a < A && qa > best) { best = qa; act = a; }      // first max wins (compute_action :70)
+                            }
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 15; ++a) if (a < A) sum = sum + h[1 + a];
+                            const float mean = __fdiv_rn(sum, (float)A);
+                            float best = (h[0] + h[1]) - mean;
+#pragma unroll
+                            for (int a = 1; a < 15; ++a) {
+                                const float qa = (h[0] + h[1 + a]) - mean;
+                                if (a < A && qa > best) { best = qa; act = a; }
+                            }
                         }
                         if (!(eps < dr.x)) act = __float_as_int(dr.y);               // q_agent.py:137-141
                         if (last) g.act_out[i] = act;

@@ -14,6 +14,7 @@
 //
 // Reference: LunarLander/dddqn.py:24-34 (forward), General/QLearning/q_learning_functions.py
 // :52-61 (targets), :35-36 (loss), :23-25 (grad + optimizer).
+#include <type_traits>
 #include "dqn_device.h"
 #include "dqn_launch.h"
 #include "dqn_per_device.h"
@@ -426,8 +427,13 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         const float *hr = lh + tid * 16;
         float sum = 0.0f;
         if constexpr (FUSE) {                                        // statically indexed (the row backward keeps qrow in registers)
+            if (m.A <= 4) {                                          // (uniform branch: 4 select-guarded links instead of 15)
 #pragma unroll
-            for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+                for (int a = 0; a < 4; ++a) if (a < m.A) sum = sum + hr[1 + a];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+            }
         } else {
             for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
         }
@@ -483,12 +489,14 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         if (tid < 16) {
             float rowloss = 0.0f;
             if (rowt) {
+                auto td_rows = [&](auto amax_tag) {
+                constexpr int AMAX = decltype(amax_tag)::value;
                 // q_learning_functions.py:55-60 + :35-36 for one row, written with statically indexed registers
-                // (unrolled to the 15-action maximum, predicated on k < A): same operations in the same order as
+                // (unrolled to AMAX = 4 or the 15-action maximum, predicated on k < A): same operations in the same order as
                 // td_row() / k_bwd_rows
-                float nqr[15], ntr[15];
+                float nqr[AMAX], ntr[AMAX];
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) {
+                for (int k2 = 0; k2 < AMAX; ++k2) {
                     nqr[k2] = k2 < A ? __hip_atomic_load(&g.nq[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                     ntr[k2] = k2 < A ? __hip_atomic_load(&g.nt[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                 }
@@ -497,7 +505,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                 const float invB = __fdiv_rn(1.0f, (float)B);
                 float best = nqr[0], nt_star = ntr[0], q_a = qrow[0];   // :55 argmax, first max wins; q[action]
 #pragma unroll
-                for (int k2 = 1; k2 < 15; ++k2) {
+                for (int k2 = 1; k2 < AMAX; ++k2) {
                     if (k2 < A && nqr[k2] > best) { best = nqr[k2]; nt_star = ntr[k2]; }
                     if (k2 == row_a) q_a = qrow[k2];
                 }
@@ -508,9 +516,9 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                 const float delta = row_r + t3;
                 if (g.td) g.td[irow] = delta;
                 if (g.td_abs) g.td_abs[irow] = fabsf(delta);
-                float gk[15], gsum = 0.0f;
+                float gk[AMAX], gsum = 0.0f;
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) {
+                for (int k2 = 0; k2 < AMAX; ++k2) {
                     gk[k2] = 0.0f;
                     if (k2 < A) {
                         const float trk = qrow[k2] + delta * (k2 == row_a ? 1.0f : 0.0f);   // :59, quirk Q4
@@ -527,7 +535,9 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                 const float gmean = __fdiv_rn(gsum, (float)A);           // dueling backward: dv = sum_a g_a ; dadv_j = g_j - mean
                 l3[tid * s3 + perm16(0)] = gsum;
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) if (k2 < A) l3[tid * s3 + perm16(1 + k2)] = gk[k2] - gmean;
+                for (int k2 = 0; k2 < AMAX; ++k2) if (k2 < A) l3[tid * s3 + perm16(1 + k2)] = gk[k2] - gmean;
+                };
+                if (A <= 4) td_rows(std::integral_constant<int, 4>{}); else td_rows(std::integral_constant<int, 15>{});
             }
             lrow[tid] = rowloss;
         }

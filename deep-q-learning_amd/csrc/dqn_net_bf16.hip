@@ -7,6 +7,7 @@
 //
 // LDS activations are plain row-major bf16 (a lane's A fragment is 8 consecutive k of one row).
 // Pointer fields of FwdPass / BwdArgs typed `float*` carry bf16 data here (pack, px, ph*, pdz*).
+#include <type_traits>
 #include "dqn_net_common.h"
 #include "dqn_per_device.h"
 
@@ -308,8 +309,13 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         const float *hr = lh + tid * 16;
         float sum = 0.0f;
         if constexpr (FUSE) {
+            if (m.A <= 4) {                                          // (uniform branch: 4 select-guarded links instead of 15)
 #pragma unroll
-            for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+                for (int a = 0; a < 4; ++a) if (a < m.A) sum = sum + hr[1 + a];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 15; ++a) if (a < m.A) sum = sum + hr[1 + a];
+            }
         } else {
             for (int a = 0; a < m.A; ++a) sum = sum + hr[1 + a];
         }
@@ -363,9 +369,11 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         if (tid < 16) {
             float rowloss = 0.0f;
             if (rowt) {
-                float nqr[15], ntr[15];
+                auto td_rows = [&](auto amax_tag) {                    // AMAX = 4 or the 15-action maximum (see k_qnet_fwd)
+                constexpr int AMAX = decltype(amax_tag)::value;
+                float nqr[AMAX], ntr[AMAX];
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) {
+                for (int k2 = 0; k2 < AMAX; ++k2) {
                     nqr[k2] = k2 < A ? __hip_atomic_load(&g.nq[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                     ntr[k2] = k2 < A ? __hip_atomic_load(&g.nt[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                 }
@@ -374,7 +382,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
                 const float invB = __fdiv_rn(1.0f, (float)B);
                 float best = nqr[0], nt_star = ntr[0], q_a = qrow[0];   // q_learning_functions.py:55 argmax, first max wins
 #pragma unroll
-                for (int k2 = 1; k2 < 15; ++k2) {
+                for (int k2 = 1; k2 < AMAX; ++k2) {
                     if (k2 < A && nqr[k2] > best) { best = nqr[k2]; nt_star = ntr[k2]; }
                     if (k2 == row_a) q_a = qrow[k2];
                 }
@@ -385,9 +393,9 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
                 const float delta = row_r + t3;
                 if (g.td) g.td[irow] = delta;
                 if (g.td_abs) g.td_abs[irow] = fabsf(delta);
-                float gk[15], gsum = 0.0f;
+                float gk[AMAX], gsum = 0.0f;
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) {
+                for (int k2 = 0; k2 < AMAX; ++k2) {
                     gk[k2] = 0.0f;
                     if (k2 < A) {
                         const float trk = qrow[k2] + delta * (k2 == row_a ? 1.0f : 0.0f);   // :59 (quirk Q4)
@@ -404,7 +412,9 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
                 const float gmean = __fdiv_rn(gsum, (float)A);
                 l3[tid * s3 + 0] = (__bf16)gsum;
 #pragma unroll
-                for (int k2 = 0; k2 < 15; ++k2) if (k2 < A) l3[tid * s3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
+                for (int k2 = 0; k2 < AMAX; ++k2) if (k2 < A) l3[tid * s3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
+                };
+                if (A <= 4) td_rows(std::integral_constant<int, 4>{}); else td_rows(std::integral_constant<int, 15>{});
             }
             lrow[tid] = rowloss;
         }
