@@ -69,6 +69,13 @@ struct ActorArgs {
 
 // ---- one sampler workgroup: 16 batch rows, 16 lanes per row, 4 tree levels per memory round trip (the descent of
 // sample_tile_coop in dqn_per_device.h: same compares / subtractions in the same order, hence the same leaves)
+// ring position of a counter: capacities are powers of two whenever a sum-tree is in use (a mask instead of the ~60-instruction
+// software 64-bit modulo in every workgroup's prologue); any other capacity takes the modulo
+__device__ __forceinline__ unsigned long long mod_cap(unsigned long long c, long long cap) {
+    const unsigned long long uc = (unsigned long long)cap;
+    return (uc & (uc - 1)) == 0 ? (c & (uc - 1)) : c % uc;
+}
+
 // the stratified uniforms of rows row0 + 16 r + g, before scaling by the tree total: k + u01 (they depend on nothing
 // the launch changes, so a sampler workgroup draws them while it waits for the tree)
 template <int NR>
@@ -202,7 +209,7 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
     const int tid = threadIdx.x;
     // the new slots are one contiguous leaf range, or two when the ring wraps (any order of inserting gives the same tree:
     // a parent is always the sum of its two current children)
-    const long long a = (long long)(c0 % (unsigned long long)e.cap);
+    const long long a = (long long)mod_cap(c0, e.cap);
     const long long seg_a[2] = {a, 0};
     const long long seg_n[2] = {a + (long long)nT < e.cap ? (long long)nT : e.cap - a, a + (long long)nT < e.cap ? 0 : a + (long long)nT - e.cap};
     // A single CU stores at ~7 B/clk: a long insert by the tree workgroup alone would be the launch's critical path
@@ -222,22 +229,22 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
         const float pmax = e.st->pmax;
         if (g.n_smp > 0) {
             for (int seg = 0; seg < 2; ++seg)
-                if (seg_n[seg] > 0) per_add_range_ends(e.tree, e.Nt, e.L, lmax, seg_a[seg], (int)seg_n[seg], pmax, lds);
+                if (seg_n[seg] > 0) per_add_range_ends(e.tree, e.Nt, e.L, lmax, seg_a[seg], (int)seg_n[seg], pmax, lds, 256);
             BSTAMP(1);
             // every sampler workgroup has stored (and released) its share of the inner nodes?
             if (tid == 0)
                 while (__hip_atomic_load(&e.st->fill_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nfill) __builtin_amdgcn_s_sleep(4);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
+            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds, 256);
             BSTAMP(2);
             __syncthreads();                                                 // every wave's tree stores (sc1) have been acknowledged
             if (tid == 0) __hip_atomic_store(&e.st->tree_ready, ticket_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds);
+            if (e.rebuild_top) per_top_wg(e.tree, e.L, lds, 256);
             BSTAMP(1);
             for (int seg = 0; seg < 2; ++seg)
-                if (seg_n[seg] > 0) { per_add_range_wg(e.tree, e.Nt, e.L, seg_a[seg], (int)seg_n[seg], pmax, lds); __syncthreads(); }
+                if (seg_n[seg] > 0) { per_add_range_wg(e.tree, e.Nt, e.L, seg_a[seg], (int)seg_n[seg], pmax, lds, 256); __syncthreads(); }
             BSTAMP(2);
         }
         BSTAMP(3);
@@ -247,7 +254,7 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
         if (wg < nfill) {
             const float pmax = e.st->pmax;
             for (int seg = 0; seg < 2; ++seg)
-                if (seg_n[seg] > 0) per_add_range_fill(e.tree, e.Nt, lmax, seg_a[seg], (int)seg_n[seg], pmax, wg, nfill);
+                if (seg_n[seg] > 0) per_add_range_fill(e.tree, e.Nt, lmax, seg_a[seg], (int)seg_n[seg], pmax, wg, nfill, 256);
             __syncthreads();                                                 // the stores (sc1) have been acknowledged
             if (tid == 0) atomicAdd(&e.st->fill_cnt, 1u);
         }
@@ -317,7 +324,7 @@ k_actor(NetDims m, ActorArgs g) {
     const int n_emit = g.T > warm ? g.T - warm : 0;
     const unsigned long long nT = (unsigned long long)n_emit * (unsigned long long)e.n, c1 = c0 + nT;
     const unsigned long long ticket_val = ec + (unsigned long long)g.T;   // flag value of THIS launch (the env step counter only grows)
-    const unsigned total_wgs = gridDim.x;
+    const unsigned total_wgs = (unsigned)(g.n_tree + g.G + g.n_smp);   // (= gridDim.x, without reading the dispatch packet)
     int role = 1, wg = (int)blockIdx.x - g.n_tree;
     if ((int)blockIdx.x < g.n_tree) role = 0;
     else if (wg >= g.G) { role = 2; wg -= g.G; }
@@ -465,7 +472,7 @@ k_actor(NetDims m, ActorArgs g) {
         for (int kq = N1; kq < 4 * KB; ++kq) BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
         ASTAMP(23);
         // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
-        const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
+        const long long a0 = (long long)mod_cap(c0, e.cap);
         bool w2_landed = false;
         s16x4 w1p[4], w2p[BF ? 4 * KB : 1];                               // bf16 mode: the slabs as four-k bf16 groups
         float bh16 = 0.0f;                                               // bf16 mode: head bias of column `lane` (wave 0)
@@ -843,7 +850,7 @@ k_actor16(NetDims m, ActorArgs g) {
     const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
     const unsigned long long nT = (unsigned long long)g.T * (unsigned long long)e.n, c1 = c0 + nT;
     const unsigned long long ticket_val = ec + (unsigned long long)g.T;
-    const unsigned total_wgs = gridDim.x;
+    const unsigned total_wgs = (unsigned)(g.n_tree + g.G + g.n_smp);   // (= gridDim.x, without reading the dispatch packet)
     int role = 1, wg = (int)blockIdx.x - g.n_tree;
     if ((int)blockIdx.x < g.n_tree) role = 0;
     else if (wg >= g.G) { role = 2; wg -= g.G; }
@@ -885,7 +892,7 @@ k_actor16(NetDims m, ActorArgs g) {
         for (int kq = 0; kq < KQ; ++kq) { const f32x4 w = ph[(long long)(kq < KQH ? kq : 0) * 64 + lane]; whf[kq] = kq < KQH ? w : z4; }
         { const float bvv = P[c15 == 0 || c15 > A ? m.o_bv : m.o_ba + c15 - 1]; bh = c15 <= A ? bvv : 0.0f; }
         float eps = e.st->epsilon;
-        const long long a0 = (long long)(c0 % (unsigned long long)e.cap);
+        const long long a0 = (long long)mod_cap(c0, e.cap);
         ASTAMP(0);
 
         auto make_draws = [&](int i0, int cnt, int t0) {                     // Philox draws of steps t0 .. t0+TC-1 (waves 1..3)

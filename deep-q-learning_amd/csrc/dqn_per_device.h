@@ -212,8 +212,8 @@ __device__ __forceinline__ void tree_st4(float4 *p, const float4 &v) {
 
 // inner nodes of levels 0 .. lmax of the leaf range [a, a+n): share `w` of `nw` (whole workgroups; w = 0 also stores the
 // few unaligned nodes at the ends of each level's run). 16-B stores for the aligned middle.
-__device__ __forceinline__ void per_add_range_fill(float *tree, long long Nt, int lmax, long long a, int n, float pmax, int w, int nw) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void per_add_range_fill(float *tree, long long Nt, int lmax, long long a, int n, float pmax, int w, int nw, int nt = (int)blockDim.x) {
+    const int tid = threadIdx.x;
     const long long first = Nt + a, last = Nt + a + n - 1;
     for (int l = 0; l <= lmax; ++l) {
         const long long lo = first >> l, hi = last >> l;
@@ -237,8 +237,8 @@ __device__ __forceinline__ void per_add_range_fill(float *tree, long long Nt, in
 
 // the two END nodes of levels 0 .. lmax (+ the parents they feed at level lmax + 1 when lmax < L - 1 is NOT wanted: the walk
 // stops after writing level lmax). One thread; outside siblings requested up front by the whole workgroup. lds: 64 floats.
-__device__ __forceinline__ void per_add_range_ends(float *tree, long long Nt, int L, int lmax, long long a, int n, float pmax, float *lds) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void per_add_range_ends(float *tree, long long Nt, int L, int lmax, long long a, int n, float pmax, float *lds, int nt = (int)blockDim.x) {
+    const int tid = threadIdx.x;
     float *bl = lds, *br = lds + 32;
     const long long first = Nt + a, last = Nt + a + n - 1;
     for (int l = tid; l < L; l += nt) {
@@ -271,15 +271,15 @@ __device__ __forceinline__ void per_add_range_ends(float *tree, long long Nt, in
 }
 
 // the whole insert by one workgroup (API path k_per_add; actor launches without sampler workgroups)
-__device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int L, long long a, int n, float pmax, float *lds) {
-    per_add_range_fill(tree, Nt, L, a, n, pmax, 0, 1);
-    per_add_range_ends(tree, Nt, L, L, a, n, pmax, lds);
+__device__ __forceinline__ void per_add_range_wg(float *tree, long long Nt, int L, long long a, int n, float pmax, float *lds, int nt = (int)blockDim.x) {
+    per_add_range_fill(tree, Nt, L, a, n, pmax, 0, 1, nt);
+    per_add_range_ends(tree, Nt, L, L, a, n, pmax, lds, nt);
 }
 
 // dense top of the tree, whole workgroup: depth TOP-1 from the depth-TOP pairs in HBM, the levels above out of an
 // LDS image of 2^TOP floats -- 256 x 68 floats on the 256-thread fast path -- (same arithmetic as k_per_top). Ends with a barrier.
-__device__ __forceinline__ void per_top_wg(float *tree, int L, float *top) {
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void per_top_wg(float *tree, int L, float *top, int nt = (int)blockDim.x) {
+    const int tid = threadIdx.x;
     const int TOP = L < PW_TOP ? L : PW_TOP;
     if (TOP == 0) return;
     if (TOP == 14 && nt == 256) {
