@@ -342,7 +342,8 @@ k_actor(NetDims m, ActorArgs g) {
         // policy's u, its random action, done, reward. None depends on the forward pass: waves 1..3 make them for a whole
         // chunk of steps up front (behind the W2 stream for the first tile) instead of inside every step.
         const int DO = (D + 3) & ~3, DW = DO + 4;                            // the four scalars sit 16-B aligned behind the observation
-        float *ldraw = lq + 64 + 4;
+        float *lpart = lq + 64 + 4;                                          // heads: the four waves' partial sums [4][64]
+        float *ldraw = lpart + 256;
         // bf16 mode: bf16 images of h1 / h2 / the heads' weights (rounded ONCE, by the lanes that produce them: a chain link
         // is then one 8-B LDS read + one MFMA, no conversion in its shadow)
         const int s1h = 16 * KB + 8, s2h = 16 * KB2 + 8;
@@ -370,6 +371,7 @@ k_actor(NetDims m, ActorArgs g) {
         const unsigned cc1 = col < (unsigned)H1 ? col : (unsigned)H1 - 1u, cc2 = col < (unsigned)H2 ? col : (unsigned)H2 - 1u;
         const int hr = lane & 3, hc = lane >> 2;                             // head chain of this lane (wave 0)
         const bool hlane = wave == 0 && hc <= A;
+        const bool hany = hc <= A;                                           // (every wave runs one of the four partial chains)
         const int nq4 = 4 * H2;
         // The W2 slab goes straight to its final registers as 16-B loads of the k-packed shadow (four consecutive k of
         // the lane's column; measured 69 B/clk/CU against 36 for dword rows): k < 64 to architectural VGPRs, the rest to
@@ -652,6 +654,33 @@ k_actor(NetDims m, ActorArgs g) {
                 }
                 LDS_BARRIER();
                 ASTAMP(3 + 4 * t);
+                if constexpr (!BF) {
+                    // heads (dddqn.py:29-30): 4 rows x (1+A) columns, each the sum of four partial fmaf chains -- chain j over
+                    // the k with (k / 4) % 4 == j (oracle: heads_row) -- one per WAVE: a quarter of the dependent chain each
+                    if (hany) {
+                        const float *ar = l2 + hr * s2 + 4 * wave, *wr = lwh + hc * s2 + 4 * wave;
+                        float acc = 0.0f;
+                        float4 ab[4], wb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            ab[q] = *reinterpret_cast<const float4 *>(ar + 16 * (q < KB2 ? q : 0));
+                            wb[q] = *reinterpret_cast<const float4 *>(wr + 16 * (q < KB2 ? q : 0));
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < KB2; ++kb) {
+                            const float4 a4 = ab[kb & 3], w4 = wb[kb & 3];
+                            if (kb + 4 < KB2) {
+                                ab[kb & 3] = *reinterpret_cast<const float4 *>(ar + 16 * (kb + 4));
+                                wb[kb & 3] = *reinterpret_cast<const float4 *>(wr + 16 * (kb + 4));
+                            }
+                            acc = fmaf(a4.x, w4.x, acc); acc = fmaf(a4.y, w4.y, acc);
+                            acc = fmaf(a4.z, w4.z, acc); acc = fmaf(a4.w, w4.w, acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        lpart[64 * wave + hr * 16 + hc] = acc;
+                    }
+                    LDS_BARRIER();
+                }
                 if (wave == 0) {
                     // everything of the policy lanes that does not depend on the forward pass, ahead of the chain (it then
                     // issues in the chain's dependency stalls instead of after it)
@@ -683,26 +712,8 @@ k_actor(NetDims m, ActorArgs g) {
                             for (int r = 0; r < 4; ++r) lq[r * 16 + lane] = acc[r] + bh16;
                         }
                     } else if (hlane) {
-                        const float *ar = l2 + hr * s2, *wr = lwh + hc * s2;
-                        float acc = 0.0f;
-                        float4 ab[4], wb[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { ab[q] = *reinterpret_cast<const float4 *>(ar + 4 * q); wb[q] = *reinterpret_cast<const float4 *>(wr + 4 * q); }
-#pragma unroll
-                        for (int kb = 0; kb < KB2; ++kb) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4 a4 = ab[q], w4 = wb[q];
-                                if (kb + 1 < KB2) {
-                                    ab[q] = *reinterpret_cast<const float4 *>(ar + 16 * (kb + 1) + 4 * q);
-                                    wb[q] = *reinterpret_cast<const float4 *>(wr + 16 * (kb + 1) + 4 * q);
-                                }
-                                acc = fmaf(a4.x, w4.x, acc); acc = fmaf(a4.y, w4.y, acc);
-                                acc = fmaf(a4.z, w4.z, acc); acc = fmaf(a4.w, w4.w, acc);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                        lq[hr * 16 + hc] = acc + bh;
+                        const float4 pp = {lpart[hr * 16 + hc], lpart[64 + hr * 16 + hc], lpart[128 + hr * 16 + hc], lpart[192 + hr * 16 + hc]};
+                        lq[hr * 16 + hc] = ((pp.x + pp.y) + (pp.z + pp.w)) + bh;
                     }
                     if (t == 1) ASTAMP(25);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order (lq)
@@ -1006,16 +1017,17 @@ k_actor16(NetDims m, ActorArgs g) {
                 if (tile == wg) ASTAMP(3 + 4 * t);
                 if (wave == 0) {
                     // heads: column 0 = val (dddqn.py:29), columns 1..A = adv (:30); then dueling combine + policy per env
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    // (four chains, the j-th MFMA of every k-block into chain j, combined (c0 + c1) + (c2 + c3): as k_qnet_fwd / heads_row)
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
                     const float *ar = l2 + c15 * sh + 4 * g4;
 #pragma unroll
                     for (int kq = 0; kq < KQ; ++kq) {
                         const float4 a4 = *reinterpret_cast<const float4 *>(ar + 16 * kq);
-                        acc = MFMA4(a4.x, whf[kq][0], acc); acc = MFMA4(a4.y, whf[kq][1], acc);
-                        acc = MFMA4(a4.z, whf[kq][2], acc); acc = MFMA4(a4.w, whf[kq][3], acc);
+                        c0 = MFMA4(a4.x, whf[kq][0], c0); c1 = MFMA4(a4.y, whf[kq][1], c1);
+                        c2 = MFMA4(a4.z, whf[kq][2], c2); c3 = MFMA4(a4.w, whf[kq][3], c3);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lh[(4 * g4 + r) * 16 + c15] = acc[r] + bh;
+                    for (int r = 0; r < 4; ++r) lh[(4 * g4 + r) * 16 + c15] = ((c0[r] + c1[r]) + (c2[r] + c3[r])) + bh;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS program order
                     if (lane < cnt) {
                         const int il = lane, i = i0 + il;
@@ -1169,7 +1181,7 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     const int KB = m.H1 <= 16 ? 1 : (m.H1 <= 32 ? 2 : (m.H1 <= 64 ? 4 : (m.H1 <= 128 ? 8 : 16)));
     const int KB2 = m.H2 <= 64 ? 4 : 16;
     size_t lds = sizeof(float) * (4 * (size_t)(DP + 4) + 4 * (size_t)(16 * KB + 4) + 4 * (size_t)(16 * KB2 + 4) +
-                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4);
+                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 256);
     const int DWh = ((m.D + 3) & ~3) + 4;
     g.TC = 6144 / (4 * DWh);                                              // draw buffer: <= 24 KB
     if (g.TC > T) g.TC = T;

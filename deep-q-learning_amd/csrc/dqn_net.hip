@@ -170,6 +170,29 @@ struct MmaLayer {
         init(pack, KQ_, CT_, wave_, lane);
         load(b0, 0);
     }
+    // the heads' layer (one column tile, whole layer preloaded): the j-th MFMA of every k-block accumulates into chain j
+    // (k with (k / 4) % 4 == j, ascending), combined as (c0 + c1) + (c2 + c3) -- four independent chains a quarter as long
+    // as the k-ordered one (oracle: heads_row)
+    __device__ __forceinline__ void finish_heads4(const float *lds_a, int stride, int lane, f32x4 &out) {
+        static_assert(TN == 1 && !PP, "heads: one tile, single chunk");
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+        const float *arow = lds_a + (lane & 15) * stride + 4 * (lane >> 4);
+        float4 a_cur = *reinterpret_cast<const float4 *>(arow);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            if (p < KQ) {
+                const float4 a4 = a_cur;
+                if (p + 1 < PF) a_cur = *reinterpret_cast<const float4 *>(arow + (p + 1 < KQ ? 16 * (p + 1) : 0));
+                c0 = MFMA4(a4.x, b0[p][0].x, c0);
+                c1 = MFMA4(a4.y, b0[p][0].y, c1);
+                c2 = MFMA4(a4.z, b0[p][0].z, c2);
+                c3 = MFMA4(a4.w, b0[p][0].w, c3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+    }
     // preloaded = every k-block was already requested with load_range<0, PF>()
     __device__ __forceinline__ void finish(const float *lds_a, int stride, int lane, f32x4 (&acc)[TN], bool preloaded = false) {
 #pragma unroll
@@ -403,11 +426,11 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
     }
     // heads: column 0 = val (dddqn.py:29), columns 1..A = adv (:30); one 16-column tile
     if (wave == 0) {
-        f32x4 acc[1];
-        LH.finish(l2, s2, lane, acc, true);
+        f32x4 acc;
+        LH.finish_heads4(l2, s2, lane, acc);
         const int c = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[0][r] + biash;
+        for (int r = 0; r < 4; ++r) lh[(4 * (lane >> 4) + r) * 16 + c] = acc[r] + biash;
     }
     if constexpr (FUSE) {
         // the row backward's weights ([wv|wa]^T, then all of W2^T into the registers layer 2 has freed): waves 1..3 request
@@ -990,7 +1013,7 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
                 const float vv = (ad.b2 * pV[e]) + (co.omb2 * (gi * gi));
                 ad.mu[i] = mm; ad.nu[i] = vv;
                 const float mhat = __fdiv_rn(mm, co.c1), vhat = __fdiv_rn(vv, co.c2);
-                float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + ad.eps);
+                float u = __fdiv_rn(mhat, sqrtf(vhat) + ad.eps);
                 float pnew = pP[e];
                 if (ad.adamw) u = u + (ad.wd * pnew);
                 pnew = pnew + (co.neglr * u);

@@ -724,7 +724,7 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
                 const float vv = (ad.b2 * pV[e]) + (co.omb2 * (gi * gi));
                 ad.mu[i] = mm; ad.nu[i] = vv;
                 const float mhat = __fdiv_rn(mm, co.c1), vhat = __fdiv_rn(vv, co.c2);
-                float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + ad.eps);
+                float u = __fdiv_rn(mhat, sqrtf(vhat) + ad.eps);
                 float pnew = pP[e];
                 if (ad.adamw) u = u + (ad.wd * pnew);
                 pnew = pnew + (co.neglr * u);

@@ -39,7 +39,8 @@ __device__ __forceinline__ float huber(float e) {              // optax.huber_lo
 }
 
 // optax scale_by_adam -> add_decayed_weights (adamw) -> scale(-lr) -> apply_updates, one element.
-// One IEEE rounding per written operation: bit-exact against the CPU restatement.
+// One IEEE rounding per written operation: bit-exact against the CPU restatement. (sqrtf, not __fsqrt_rn: in this
+// toolchain the intrinsic is the 1-ulp native square root; sqrtf and `/` are the correctly rounded forms.)
 struct AdamCoef { float c1, c2, omb1, omb2, neglr; };
 
 __device__ __forceinline__ AdamCoef adam_coef(const DqnState *st, float b1, float b2, double *b1pow, double *b2pow) {
@@ -54,7 +55,7 @@ __device__ __forceinline__ float adam_elem(const AdamCoef &c, float g, float *P,
     const float vv = (b2 * nu[i]) + (c.omb2 * (gi * gi));
     mu[i] = mm; nu[i] = vv;
     const float mhat = __fdiv_rn(mm, c.c1), vhat = __fdiv_rn(vv, c.c2);
-    float u = __fdiv_rn(mhat, __fsqrt_rn(vhat) + eps);
+    float u = __fdiv_rn(mhat, sqrtf(vhat) + eps);
     float p = P[i];
     if (adamw) u = u + (wd * p);
     p = p + (c.neglr * u);

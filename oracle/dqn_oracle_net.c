@@ -3,7 +3,8 @@
  * TEST INFRASTRUCTURE ONLY (see dqn_oracle.h). PARITY UNPINNED (see dqn_oracle.h).
  *
  * f32 throughout. Dot products are k-ordered fmaf chains starting from 0 (the same
- * arithmetic as gfx950's v_mfma_f32_*_f32), bias added afterwards (hk.Linear: x@w + b).
+ * arithmetic as gfx950's v_mfma_f32_*_f32), bias added afterwards (hk.Linear: x@w + b);
+ * the heads' K = hidden2 sums are four such chains over interleaved k groups (heads_row).
  * Everything else is one IEEE rounding per operation (-ffp-contract=off).
  */
 #include "dqn_oracle.h"
@@ -36,6 +37,18 @@ static void linear_row(const float *x, const float *w, const float *b, int K, in
     for (int n = 0; n < N; ++n) y[n] = y[n] + b[n];
 }
 
+/* The two heads (dddqn.py:29-30; K = hidden2, a multiple of 16): four partial fmaf chains from 0, chain j over the k with
+ * (k / 4) % 4 == j in ascending order, combined as ((c0 + c1) + (c2 + c3)) + b[n]. On the GPU chain j is the j-th
+ * v_mfma_f32_16x16x4_f32 of every 16-deep k-block (dqn_net.hip) / wave j of a k_actor workgroup: a quarter of the dependent
+ * chain length of the plain k-ordered sum. */
+static void heads_row(const float *x, const float *w, const float *b, int K, int N, float *y) {
+    for (int n = 0; n < N; ++n) {
+        float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < K; ++k) c[(k >> 2) & 3] = fmaf(x[k], w[(int64_t)k * N + n], c[(k >> 2) & 3]);
+        y[n] = ((c[0] + c[1]) + (c[2] + c[3])) + b[n];
+    }
+}
+
 void orc_forward(orc_dims m, const float *P, const float *x, int32_t B,
                  float *q, float *h1_out, float *h2_out) {
     /* LunarLander/dddqn.py:24-31 */
@@ -49,8 +62,8 @@ void orc_forward(orc_dims m, const float *P, const float *x, int32_t B,
         linear_row(h1, P + o.w2, P + o.b2, m.H1, m.H2, h2);                    /* :27 */
         for (int j = 0; j < m.H2; ++j) h2[j] = h2[j] > 0.0f ? h2[j] : 0.0f;   /* :28 */
         float v;
-        linear_row(h2, P + o.wv, P + o.bv, m.H2, 1, &v);                       /* :29 */
-        linear_row(h2, P + o.wa, P + o.ba, m.H2, m.A, adv);                    /* :30 */
+        heads_row(h2, P + o.wv, P + o.bv, m.H2, 1, &v);                        /* :29 */
+        heads_row(h2, P + o.wa, P + o.ba, m.H2, m.A, adv);                     /* :30 */
         float sum = 0.0f;
         for (int a = 0; a < m.A; ++a) sum = sum + adv[a];
         const float mean = sum / (float)m.A;
