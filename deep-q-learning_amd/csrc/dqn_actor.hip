@@ -680,6 +680,28 @@ k_actor(NetDims m, ActorArgs g) {
                         lpart[64 * wave + hr * 16 + hc] = acc;
                     }
                     LDS_BARRIER();
+                } else {
+                    // bf16 mode: the same split on v_mfma_f32_4x4x4_16b_bf16 -- wave w takes the w-th four-k group of every
+                    // 16-deep k-block; lane l supplies column l of [wv|wa] (lanes past 1+A: a duplicate of column A, result
+                    // unused) and row l&3 of h2; acc[r] of lane l = partial head l of row r
+                    const int hcl = lane <= A ? lane : A;
+                    const s16x4 *ar = reinterpret_cast<const s16x4 *>(l2h + (lane & 3) * s2h) + wave, *wr = reinterpret_cast<const s16x4 *>(lwh16 + hcl * s2h) + wave;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    s16x4 ab[4], wb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ab[q] = ar[4 * (q < KB2 ? q : 0)]; wb[q] = wr[4 * (q < KB2 ? q : 0)]; }
+#pragma unroll
+                    for (int kb = 0; kb < KB2; ++kb) {
+                        const s16x4 a4 = ab[kb & 3], w4 = wb[kb & 3];
+                        if (kb + 4 < KB2) { ab[kb & 3] = ar[4 * (kb + 4)]; wb[kb & 3] = wr[4 * (kb + 4)]; }
+                        acc = MFMA4B(a4, w4, acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (lane <= A) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) lpart[64 * wave + r * 16 + lane] = acc[r];
+                    }
+                    LDS_BARRIER();
                 }
                 if (wave == 0) {
                     // everything of the policy lanes that does not depend on the forward pass, ahead of the chain (it then
@@ -689,27 +711,10 @@ k_actor(NetDims m, ActorArgs g) {
                     int32_t *p_act = e.actions + pk; float *p_rew = e.rewards + pk; uint8_t *p_done = e.dones + pk;
                     // heads (dddqn.py:29-30): 4 rows x (1+A) columns = 4*(1+A) fmaf chains over hidden2, one per lane
                     if constexpr (BF) {
-                        // bf16 mode: one 4x4x4 chain for all of them -- lane l supplies column l of [wv|wa] (lanes past 1+A:
-                        // a duplicate of column A, result unused) and row l&3 of h2; acc[r] of lane l = head l of row r
-                        const int hcl = lane <= A ? lane : A;
-                        const s16x4 *ar = reinterpret_cast<const s16x4 *>(l2h + (lane & 3) * s2h), *wr = reinterpret_cast<const s16x4 *>(lwh16 + hcl * s2h);
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        s16x4 ab[4], wb[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { ab[q] = ar[q]; wb[q] = wr[q]; }
-#pragma unroll
-                        for (int kb = 0; kb < KB2; ++kb) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const s16x4 a4 = ab[q], w4 = wb[q];
-                                if (kb + 1 < KB2) { ab[q] = ar[4 * (kb + 1) + q]; wb[q] = wr[4 * (kb + 1) + q]; }
-                                acc = MFMA4B(a4, w4, acc);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
                         if (lane <= A) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) lq[r * 16 + lane] = acc[r] + bh16;
+                            for (int r = 0; r < 4; ++r)
+                                lq[r * 16 + lane] = ((lpart[r * 16 + lane] + lpart[64 + r * 16 + lane]) + (lpart[128 + r * 16 + lane] + lpart[192 + r * 16 + lane])) + bh16;
                         }
                     } else if (hlane) {
                         const float4 pp = {lpart[hr * 16 + hc], lpart[64 + hr * 16 + hc], lpart[128 + hr * 16 + hc], lpart[192 + hr * 16 + hc]};
