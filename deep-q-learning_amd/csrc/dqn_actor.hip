@@ -364,7 +364,9 @@ k_actor(NetDims m, ActorArgs g) {
             return i32x4{(int)(unsigned)(b & 0xffffffffull), (int)(unsigned)(b >> 32), bytes, 0x00020000};
         };
         const i32x4 rsP = mkrs(P, (int)(m.P * 4)), rsW1 = mkrs(P + m.o_w1, D * H1 * 4), rsX = mkrs(e.env_obs, e.n * D * 4),
-                    rsH = mkrs(g.pack + m.p_wht, 16 * H2 * 4), rsW2 = mkrs(g.pack + m.p_w2k, H1 * H2 * 4);
+                    rsH = mkrs(g.pack + m.p_wht, 16 * H2 * 4),
+                    rsW2 = BF ? mkrs(g.pack + m.pack_floats, H1 * H2 * 2)                  // bf16 mode: eight k per 16 bytes, ready-made
+                              : mkrs(g.pack + m.p_w2k, H1 * H2 * 4);
 #define BLD1(dst, voff, rs, soff) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff))
 #define BLD4(cls, dst, voff, rs, soff) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : cls(dst) : "v"(voff), "s"(rs), "s"(soff))
         const unsigned col = 64u * wave + lane;
@@ -377,12 +379,22 @@ k_actor(NetDims m, ActorArgs g) {
         // the lane's column; measured 69 B/clk/CU against 36 for dword rows): k < 64 to architectural VGPRs, the rest to
         // accumulation VGPRs (the ISA addresses 256 of each; the matrix core reads its B operand from either file; the
         // compiler would stage every row in an architectural VGPR first: spills, serialised copies).
-        f32x4 w2q[4 * KB];
-        constexpr int N1 = 4 * KB < 32 ? 4 * KB : 32;          // first part of the slab; the rest follows the small operands
+        // bf16 mode: the slab is the bf16 shadow the optimizer keeps (eight consecutive k of the column per 16-B load): half
+        // the requests, nothing to convert
+        f32x4 w2q[BF ? 1 : 4 * KB], w2q8[BF ? 2 * KB : 1];
+        constexpr int N1 = BF ? 0 : (4 * KB < 32 ? 4 * KB : 32);   // first part of the slab; the rest follows the small operands
         const int vw2 = (int)(cc2 * 16u);
+        if constexpr (BF) {
 #pragma unroll
-        for (int kq = 0; kq < N1; ++kq) {
-            if (kq < 16) BLD4("=v", w2q[kq], vw2, rsW2, kq * H2 * 16); else BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
+            for (int u = 0; u < 2 * KB; ++u) {           // (as below: the later half straight to accumulation VGPRs -- an "=v" result the
+                if (u < 16) BLD4("=v", w2q8[u], vw2, rsW2, u * H2 * 16);   //  allocator parks there is copied before its data has arrived)
+                else BLD4("=a", w2q8[u], vw2, rsW2, u * H2 * 16);
+            }
+        } else {
+#pragma unroll
+            for (int kq = 0; kq < N1; ++kq) {
+                if (kq < 16) BLD4("=v", w2q[kq], vw2, rsW2, kq * H2 * 16); else BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
+            }
         }
         float x0, w1r[16], b1r, b2r, bh;
         f32x4 whv[4];
@@ -471,7 +483,7 @@ k_actor(NetDims m, ActorArgs g) {
         if (tid < 4 * sx) lx[tid] = x0;                                      // first tile's rows
         ASTAMP(22);
 #pragma unroll
-        for (int kq = N1; kq < 4 * KB; ++kq) BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
+        for (int kq = N1; kq < (BF ? 0 : 4 * KB); ++kq) BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
         ASTAMP(23);
         // ring slot of env i at step t = (c0 + t*n + i) mod capacity; T*n <= capacity, so one conditional subtraction
         const long long a0 = (long long)mod_cap(c0, e.cap);
@@ -574,10 +586,13 @@ k_actor(NetDims m, ActorArgs g) {
                     if constexpr (BF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     w2_landed = true; ASTAMP(24);
                     if constexpr (BF) {
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-                        for (int kq = 0; kq < 4 * KB; ++kq) {
-                            if (kq < 16) asm volatile("" : "+v"(w2q[kq])); else asm volatile("" : "+a"(w2q[kq]));
-                            w2p[kq] = cvt4(w2q[kq][0], w2q[kq][1], w2q[kq][2], w2q[kq][3]);
+                        for (int u = 0; u < 2 * KB; ++u) {
+                            if (u < 16) asm volatile("" : "+v"(w2q8[u])); else asm volatile("" : "+a"(w2q8[u]));
+                            const s16x8 h8 = __builtin_bit_cast(s16x8, w2q8[u]);
+                            w2p[2 * u] = s16x4{h8[0], h8[1], h8[2], h8[3]};
+                            w2p[2 * u + 1] = s16x4{h8[4], h8[5], h8[6], h8[7]};
                         }
                     }
                 }

@@ -106,7 +106,7 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pack) {
     if (h->bf16) {
         launch_pack_bf16(s, h->m, params, pack);
-        if (pack == h->pack) launch_pack(s, h->m, params, h->pack_act);   // the actor kernel reads f32 shadows of the online net
+        if (pack == h->pack) { launch_pack(s, h->m, params, h->pack_act); launch_pack_w2k16(s, h->m, params, h->pack_act); }   // the actor kernel reads f32 shadows of the online net
     } else launch_pack(s, h->m, params, pack);
 }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
@@ -184,7 +184,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     const size_t pack_bytes = h->bf16 ? (size_t)bf16_pack_elems(h->m) * 2 : (size_t)h->m.pack_floats * 4;
     h->pack_bytes = pack_bytes;
     add(&h->pack, pack_bytes); add(&h->pack_t, pack_bytes);
-    if (h->bf16) add(&h->pack_act, (size_t)h->m.pack_floats * 4);
+    if (h->bf16) add(&h->pack_act, (size_t)h->m.pack_floats * 4 + (size_t)h->m.H1 * h->m.H2 * 2);   // f32 shadows + bf16 k-packed W2
     add(&h->states, N * D * 4, DQN_BUF_STATES); add(&h->observations, N * D * 4, DQN_BUF_OBSERVATIONS);
     add(&h->rewards, N * 4, DQN_BUF_REWARDS); add(&h->actions, N * 4, DQN_BUF_ACTIONS);
     add(&h->dones, N, DQN_BUF_DONES);

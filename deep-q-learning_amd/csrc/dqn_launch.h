@@ -80,6 +80,7 @@ struct AdamArgs {           // optimizer applied in the dW epilogue (single-GPU 
 };
 
 void launch_pack(hipStream_t s, const NetDims &m, const float *params, float *pack);
+void launch_pack_w2k16(hipStream_t s, const NetDims &m, const float *params, float *pack_act);   // bf16 mode (dqn_net_bf16.hip)
 // fuse != NULL (f32, three passes, 3 * ceil(B/16) <= 256, batch weights final before the launch): the pass-0 workgroups
 // also run the row backward of their tiles (k_bwd_rows' work); tile_cnt = ceil(B/16) zeroed counters
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,

@@ -793,3 +793,15 @@ void launch_adam_bf16(hipStream_t s, const NetDims &m, DqnState *st, float *para
     DQN_LAUNCH(k_adam16, dim3(blocks), dim3(256), 0, s, m, make_dims16(m), st, params, grad, mu, nu,
                        reinterpret_cast<__bf16 *>(pack), adamw, b1, b2, eps, wd, grad_scale, pack_act);
 }
+
+// bf16 k-packed W2 behind the f32 actor shadows (scatter_actor_packs keeps it current afterwards)
+__global__ void k_pack_w2k16(NetDims m, const float *__restrict__ params, float *__restrict__ pack_act) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= m.H1 * m.H2) return;
+    const int k = u / m.H2, n = u - k * m.H2;
+    reinterpret_cast<__bf16 *>(pack_act + m.pack_floats)[((long long)(k >> 3) * m.H2 + n) * 8 + (k & 7)] = (__bf16)params[m.o_w2 + u];
+}
+void launch_pack_w2k16(hipStream_t s, const NetDims &m, const float *params, float *pack_act) {
+    hipLaunchKernelGGL(k_pack_w2k16, dim3((m.H1 * m.H2 + 255) / 256), dim3(256), 0, s, m, params, pack_act);
+}
+

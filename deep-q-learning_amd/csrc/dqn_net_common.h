@@ -76,6 +76,9 @@ __device__ __forceinline__ void scatter_actor_packs(const NetDims &m, int i, flo
     if (i >= o_w2 && i < o_b2) {
         const int u = i - o_w2, k = u / m.H2, n = u - k * m.H2;
         packf[m.p_w2k + ((long long)(k >> 2) * m.H2 + n) * 4 + (k & 3)] = v;
+        // behind the f32 shadows: W2 once more as bf16, eight consecutive k of a column per 16 bytes -- the bf16 actor's
+        // register slab arrives ready-made (half the bytes of the f32 shadow, no conversion in its prologue)
+        reinterpret_cast<__bf16 *>(packf + m.pack_floats)[((long long)(k >> 3) * m.H2 + n) * 8 + (k & 7)] = (__bf16)v;
     } else if (i >= o_wv && i < o_bv) {
         packf[m.p_wht + pidx(1, 0, i - o_wv)] = v;
     } else if (i >= o_wa && i < o_ba) {
