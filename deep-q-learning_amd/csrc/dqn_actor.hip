@@ -396,9 +396,9 @@ k_actor(NetDims m, ActorArgs g) {
                 if (kq < 16) BLD4("=v", w2q[kq], vw2, rsW2, kq * H2 * 16); else BLD4("=a", w2q[kq], vw2, rsW2, kq * H2 * 16);
             }
         }
-        float x0, w1r[16], b1r, b2r, bh;
+        float x0, w1r[16], b1r, b2r, bh, bh16r = 0.0f;
         f32x4 whv[4];
-        int vx, v1, v2, vh, vq[4];
+        int vx, v1, v2, vh, vh16 = 0, vq[4];
         {
             // element tid of the first tile's lx image (out of range => 0.0: padding columns, rows past n)
             const int il = tid / sx, el = tid - il * sx, i = 4 * wg + il;
@@ -411,6 +411,10 @@ k_actor(NetDims m, ActorArgs g) {
             BLD1(b2r, v2, rsP, (int)m.o_b2 * 4);
             vh = ((hc == 0 || hc > A) ? (int)m.o_bv : (int)m.o_ba + hc - 1) * 4;
             BLD1(bh, vh, rsP, 0);
+            if constexpr (BF) {                                               // bf16 mode: head bias of column `lane`
+                vh16 = ((lane == 0 || lane > A) ? (int)m.o_bv : (int)m.o_ba + lane - 1) * 4;
+                BLD1(bh16r, vh16, rsP, 0);
+            }
             // heads, from the fragment-ordered transposed shadow (dqn_net.hip: packed(WH^T), K = 1+A padded to 16, C = H2):
             // float4 number ct*64 + ln holds WH^T[4j + (ln>>4)][16ct + (ln&15)], j = 0..3
 #pragma unroll
@@ -418,7 +422,7 @@ k_actor(NetDims m, ActorArgs g) {
         }
         // (the address registers of the requests above stay allocated until here: were one of them reused as a destination
         // of the slab requests, the compiler would put a full wait in front of that request)
-        asm volatile("" :: "v"(vx), "v"(v1), "v"(v2), "v"(vh), "v"(vq[0]), "v"(vq[1]), "v"(vq[2]), "v"(vq[3]));
+        asm volatile("" :: "v"(vx), "v"(v1), "v"(v2), "v"(vh), "v"(vh16), "v"(vq[0]), "v"(vq[1]), "v"(vq[2]), "v"(vq[3]));
         float eps = e.st->epsilon;
         // ---- Philox draws of steps t0 .. t0+TC-1 of a tile (waves 1..3): for the first tile right here, while the parameter
         // requests above are in flight
@@ -452,13 +456,14 @@ k_actor(NetDims m, ActorArgs g) {
         if (wg < g.tiles) make_draws(4 * wg, e.n - 4 * wg < 4 ? e.n - 4 * wg : 4, 0);
         ASTAMP(20);
         // zero images: h1 / h2 columns past hidden1 / hidden2 and the heads' padding stay zero for the whole launch
-        for (int t = tid; t < 4 * s1 + 4 * s2 + (A + 1) * s2; t += 256) l1[t] = 0.0f;
-        if constexpr (BF) for (int t = tid; t < 4 * s1h + 4 * s2h + (A + 1) * s2h; t += 256) l1h[t] = (__bf16)0.0f;
+        // (16-B stores: every stride is a multiple of four floats / eight bf16, the images start 16-B aligned)
+        for (int t = tid; t < (4 * s1 + 4 * s2 + (A + 1) * s2) / 4; t += 256) reinterpret_cast<float4 *>(l1)[t] = float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) for (int t = tid; t < (4 * s1h + 4 * s2h + (A + 1) * s2h) / 8; t += 256) reinterpret_cast<float4 *>(l1h)[t] = float4{0.f, 0.f, 0.f, 0.f};
         LDS_BARRIER();
         ASTAMP(21);
         // the small operands are the youngest requests: everything issued so far has landed after this wait; the registers
         // are operands of the wait (or of a pin right behind it) so that no use of them can be scheduled ahead of it
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(whv[0]), "+v"(whv[1]), "+v"(whv[2]), "+v"(whv[3]) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(bh16r), "+v"(whv[0]), "+v"(whv[1]), "+v"(whv[2]), "+v"(whv[3]) :: "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
         asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
@@ -493,8 +498,8 @@ k_actor(NetDims m, ActorArgs g) {
         if constexpr (BF) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) w1p[kq] = cvt4(w1r[4 * kq], w1r[4 * kq + 1], w1r[4 * kq + 2], w1r[4 * kq + 3]);
-            if (wave == 0 && lane <= A) bh16 = lane == 0 ? P[m.o_bv] : P[m.o_ba + lane - 1];
-            asm volatile("" : "+v"(bh16));                               // (tracked load: waited for here, not in the step loop)
+            bh16 = bh16r;                                                // (requested with the small operands of the prologue)
+            asm volatile("" : "+v"(bh16));
         }
         const int hpos0 = NSTEP ? (int)(hs0 % (unsigned long long)e.n_step) : 0;   // one 64-bit modulo per launch, not per step
 
