@@ -10,7 +10,8 @@
 //     instruction -- the narrowest row tile the matrix core offers at the full f32 rate, so a 256x256 layer costs
 //     256 issues per wave instead of the 1024 of a 16-row tile. One fused multiply-add per (row, column, k) in
 //     ascending k: bit-for-bit the fmaf chain of the CPU restatement (and of the 16x16x4 kernels of dqn_net.hip);
-//   * the two skinny heads (4 rows x (1+A) columns, K = H2) run as 4*(1+A) VALU fmaf chains out of LDS;
+//   * the two skinny heads (4 rows x (1+A) columns, K = H2) run as VALU fmaf chains out of LDS: four partial chains per output
+//     (k groups of four, chain j = (k/4) % 4, one per wave), combined (c0+c1)+(c2+c3) -- the oracle's heads_row;
 //   * the env state never leaves LDS between steps; ring rows go straight to their (deterministic) slots
 //     counter + t*n + i (replay_buffer.py:58-65).
 // Synthetic env: no physics. Per env i and vector step c: obs' ~ N(0,1)^D, r ~ N(0,1) (+-100 on terminals),

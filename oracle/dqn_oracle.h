@@ -77,7 +77,7 @@ void orc_per_update(orc_per *t, const int32_t *idx, const float *td_abs, int32_t
 void orc_per_set(orc_per *t, const int32_t *idx, const float *prio, int32_t B);
 
 
-/* ---- dueling Q-network + DDDQN update (f32, k-ordered fmaf chains) ---- */
+/* ---- dueling Q-network + DDDQN update (f32, k-ordered fmaf chains; heads: four interleaved chains, see heads_row) ---- */
 /* flat parameter layout (haiku leaf order, w is [in,out] row-major):
  *   w1[D*H1] b1[H1] w2[H1*H2] b2[H2] wv[H2] bv[1] wa[H2*A] ba[A]          */
 typedef struct { int32_t D, H1, H2, A; } orc_dims;
