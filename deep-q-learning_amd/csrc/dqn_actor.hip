@@ -516,9 +516,9 @@ k_actor(NetDims m, ActorArgs g) {
             LDS_BARRIER();
             ASTAMP(1);
 
-            for (int t = 0; t < g.T; ++t) {
-                if (t % g.TC == 0 && !(tile == wg && t == 0)) make_draws(i0, cnt, t);   // (first chunk of the first tile: made in the prologue)
-                const float *dstep = ldraw + ((t % g.TC) * 4) * DW;
+            for (int t = 0, tc = 0; t < g.T; ++t, tc = tc + 1 == g.TC ? 0 : tc + 1) {   // tc = t % TC without the division
+                if (tc == 0 && !(tile == wg && t == 0)) make_draws(i0, cnt, t);   // (first chunk of the first tile: made in the prologue)
+                const float *dstep = ldraw + (tc * 4) * DW;
                 const bool last = t == g.T - 1;
                 const unsigned long long ect = ec + (unsigned long long)t;
                 const bool emit = !NSTEP || t >= warm;                          // (n-step warm-up: the step is only filed)
@@ -983,9 +983,9 @@ k_actor16(NetDims m, ActorArgs g) {
             LDS_BARRIER();
             if (tile == wg) ASTAMP(1);
 
-            for (int t = 0; t < g.T; ++t) {
-                if (t % g.TC == 0) make_draws(i0, cnt, t);
-                const float *dstep = ldraw + ((t % g.TC) * 16) * DW;
+            for (int t = 0, tc = 0; t < g.T; ++t, tc = tc + 1 == g.TC ? 0 : tc + 1) {   // tc = t % TC without the division
+                if (tc == 0) make_draws(i0, cnt, t);
+                const float *dstep = ldraw + (tc * 16) * DW;
                 const bool last = t == g.T - 1;
                 const unsigned long long ect = ec + (unsigned long long)t;
                 const long long at = a0 + (long long)t * e.n + i0;
