@@ -539,6 +539,7 @@ k_actor(NetDims m, ActorArgs g) {
                     for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
                 }
                 asm volatile("" : "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(eps));
+                if (t == 1) ASTAMP(30);
                 // layer 1: h1 = relu(x @ w1 + b1)                              dddqn.py:25-26
                 {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -577,6 +578,7 @@ k_actor(NetDims m, ActorArgs g) {
                     } else {
                         for (int k = 0; k < D; ++k) acc = MFMA1(ar[k], P[m.o_w1 + (long long)k * H1 + cc1], acc);
                     }
+                    if (t == 1) ASTAMP(31);
                     if (col < (unsigned)H1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -586,6 +588,7 @@ k_actor(NetDims m, ActorArgs g) {
                         }
                     }
                 }
+                if (t == 1) ASTAMP(32);
                 if (!w2_landed) {
                     // bf16 mode converts the whole slab once: wait for all of it. Exact mode: the layer-2 chain below waits
                     // for the slab quarter by quarter, so the first step's chain runs while the rest is still arriving.

@@ -57,6 +57,9 @@ def main():
     if st[7, 25, 0]:
         print(f"k_actor step 1 heads phase (cycles since its L2 done): chain done +{int(st[7, 25, 0] - st[7, 7, 0])}, "
               f"draw flags seen +{int(st[7, 26, 0] - st[7, 7, 0])}, policy + stores done +{int(st[7, 8, 0] - st[7, 7, 0])}")
+    if st[7, 30, 0]:
+        print("k_actor step 1, layer-1 phase (cycles since the previous step's end): " + ", ".join(
+            f"{lab} +{int(st[7, i, 0] - st[7, 5, 0])}" for lab, i in (("loop top done", 30), ("MFMAs done", 31), ("epilogue stored", 32), ("barrier passed", 6))))
     if st[7, 27, 0]:
         print(f"k_actor step 1, wave 1 (real-time ns since the step's L2 done): draws start {int(st[7, 27, 1] - st[7, 7, 1]) * 10}, "
               f"flag written {int(st[7, 28, 1] - st[7, 7, 1]) * 10}; wave 0: chain done {int(st[7, 25, 1] - st[7, 7, 1]) * 10}, "
