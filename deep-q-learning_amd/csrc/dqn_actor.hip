@@ -321,6 +321,7 @@ k_actor(NetDims m, ActorArgs g) {
     // n-step returns: a vector step adds rows only once n_step steps are on file, i.e. not during the first `warm` steps
     // after dqn_env_reset (n_step == 1: warm = 0, every step adds its n rows)
     const unsigned long long hs0 = NSTEP ? e.st->hist_steps : 0ull;
+    unsigned int ticket = 0u;                    // this workgroup's arrival ticket (thread 0; see the commit at the end)
     const int warm = (NSTEP && hs0 + 1ull < (unsigned long long)e.n_step) ? (int)((unsigned long long)e.n_step - 1ull - hs0) : 0;
     const int n_emit = g.T > warm ? g.T - warm : 0;
     const unsigned long long nT = (unsigned long long)n_emit * (unsigned long long)e.n, c1 = c0 + nT;
@@ -467,6 +468,14 @@ k_actor(NetDims m, ActorArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(b1r), "+v"(b2r), "+v"(bh), "+v"(bh16r), "+v"(whv[0]), "+v"(whv[1]), "+v"(whv[2]), "+v"(whv[3]) :: "memory");
 #pragma unroll
         for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(w1r[k]));
+        // The commit at the end of the launch needs "every workgroup has READ the counters", not "has finished": an actor
+        // workgroup takes its ticket here -- every wave is past the barrier above, i.e. has c0 / ec (/ hs0) in registers --
+        // and looks at it at the end, so the returning atomic's round trip is not the tail of the launch.
+        if (tid == 0) {
+            unsigned int one = 1u;
+            asm volatile("" : "+s"(one) : "s"(c0), "s"(ec), "s"(hs0));
+            ticket = atomicAdd(&e.st->arrive, one);
+        }
         asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
                                                  // where a full vmcnt wait would also wait for the previous step's ring stores)
         // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
@@ -857,7 +866,7 @@ k_actor(NetDims m, ActorArgs g) {
     // workgroup that reaches this barrier has finished reading them)
     LDS_BARRIER();
     if (tid == 0) {
-        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
+        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
@@ -890,6 +899,7 @@ k_actor16(NetDims m, ActorArgs g) {
     const unsigned long long c0 = e.st->ring_counter, ec = e.st->env_ctr;
     const unsigned long long nT = (unsigned long long)g.T * (unsigned long long)e.n, c1 = c0 + nT;
     const unsigned long long ticket_val = ec + (unsigned long long)g.T;
+    unsigned int ticket = 0u;                    // arrival ticket (thread 0), taken early by actor workgroups as in k_actor
     const unsigned total_wgs = (unsigned)(g.n_tree + g.G + g.n_smp);   // (= gridDim.x, without reading the dispatch packet)
     int role = 1, wg = (int)blockIdx.x - g.n_tree;
     if ((int)blockIdx.x < g.n_tree) role = 0;
@@ -985,6 +995,11 @@ k_actor16(NetDims m, ActorArgs g) {
             if (e.kind == 1 && tid < 16) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
             LDS_BARRIER();
             if (tile == wg) ASTAMP(1);
+            if (tile == wg && tid == 0) {                                    // arrival ticket, early (see k_actor): every wave has c0 / ec
+                unsigned int one = 1u;
+                asm volatile("" : "+s"(one) : "s"(c0), "s"(ec));
+                ticket = atomicAdd(&e.st->arrive, one);
+            }
 
             for (int t = 0, tc = 0; t < g.T; ++t, tc = tc + 1 == g.TC ? 0 : tc + 1) {   // tc = t % TC without the division
                 if (tc == 0) make_draws(i0, cnt, t);
@@ -1136,7 +1151,7 @@ k_actor16(NetDims m, ActorArgs g) {
     }
     LDS_BARRIER();
     if (tid == 0) {
-        const unsigned int ticket = atomicAdd(&e.st->arrive, 1u);
+        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65

@@ -991,6 +991,15 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
     redb[wave][lane] = bsum;
     LDS_BARRIER();
+    // arrival ticket for the optimizer-counter commit at the end, taken HERE: every wave of the block is past its operand
+    // waits, hence has the coefficients it requested before them; the returning atomic's round trip then hides behind the
+    // epilogue instead of being the tail of the launch
+    unsigned int ticket = 0u;
+    if (ad.P && tid == 0) {
+        unsigned int one = 1u;
+        asm volatile("" : "+v"(one) : "v"(co.c1), "v"(co.c2), "v"(co.neglr));
+        ticket = atomicAdd(&st->arrive, one);
+    }
     // reduce the four K-slices in wave order (fixed => deterministic), then write / apply
     {
         const int rr = tid >> 4, c = tid & 15;
@@ -1042,13 +1051,9 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
         }
     }
     if (ad.P) {
-        // commit the optimizer counters once every block has read them (its element updates above
-        // depend on the coefficients, so passing this barrier implies the reads are complete)
-        LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
-        if (tid == 0) {
-            const unsigned int ticket = atomicAdd(&st->arrive, 1u);
-            if (ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
-        }
+        // commit the optimizer counters once every block has read them: the block that drew the last ticket (tickets are
+        // taken after the operand waits, above) writes them
+        if (tid == 0 && ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
     }
     STAMP(6, 3);
 }

@@ -704,6 +704,12 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
     for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
     redb[wave][lane] = bsum;
     LDS_BARRIER();
+    unsigned int ticket = 0u;                                    // arrival ticket for the commit at the end, taken early (see k_dw)
+    if (ad.P && tid == 0) {
+        unsigned int one = 1u;
+        asm volatile("" : "+v"(one) : "v"(co.c1), "v"(co.c2), "v"(co.neglr));
+        ticket = atomicAdd(&st->arrive, one);
+    }
     {
         const int rr = tid >> 4, c = tid & 15;
         const int sl = ((rr >> 2) << 4) | c, sr = rr & 3;
@@ -746,11 +752,7 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
         }
     }
     if (ad.P) {
-        LDS_BARRIER();                                           // (a barrier only: no need to drain this block's stores first)
-        if (tid == 0) {
-            const unsigned int ticket = atomicAdd(&st->arrive, 1u);
-            if (ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
-        }
+        if (tid == 0 && ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
     }
 }
 
