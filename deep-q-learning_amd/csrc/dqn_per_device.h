@@ -12,6 +12,15 @@
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
 
+// (-DDQN_STAMPS: the wave that owns chunk 0 -- in k_dw a surplus workgroup, not block 0)
+#ifdef DQN_STAMPS
+#define PWSTAMP(S)                                                                              \
+    do { if (chunk == 0 && (threadIdx.x & 63) == 0) {                                            \
+             g_stamps[4][S][0] = __builtin_amdgcn_s_memtime();                                   \
+             g_stamps[4][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define PWSTAMP(S) do { } while (0)
+#endif
 // one wave = one 64-position chunk of the batch (chunk index `chunk`); called by k_per_write_sorted and by
 // the surplus workgroups of k_dw (the write-back then shares a launch with the weight gradients)
 __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree, long long N, int L,
@@ -19,7 +28,7 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
                                                       int B, int mode, float alpha, float eps, int chunk) {
     const int lane = threadIdx.x & 63, base = chunk * 64;
     const int TOP = L < PW_TOP ? L : PW_TOP, SH = L - TOP;       // depth-TOP subtree id = leaf >> SH
-    STAMP(4, 0);
+    PWSTAMP(0);
     // ---- which items does this wave own?
     const int i0 = base + lane;
     const int my = i0 < B ? idx[i0] : -1;
@@ -45,7 +54,7 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
     }
     const int total = (last_chunk + 1 - first) + ext;
     float lmax = 0.0f;
-    STAMP(4, 1);
+    PWSTAMP(1);
 
     if (total <= 64) {
         // ---- fast path: one item per lane, registers only
@@ -62,7 +71,7 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
             if (live && lane + 1 < total && xn == x) live = false;
         }
         if (live) tree[x] = v;
-        STAMP(4, 2);
+        PWSTAMP(2);
 #pragma unroll
         for (int l = 0; l < PW_BOT; ++l) {
             if (l >= SH) break;
@@ -107,11 +116,11 @@ __device__ __forceinline__ void per_write_sorted_wave(DqnState *st, float *tree,
             }
         }
     }
-    STAMP(4, 3);
+    PWSTAMP(3);
     // running max priority: order-independent (positive floats order like their bit patterns)
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
     if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(&st->pmax), __float_as_uint(lmax));
-    STAMP(4, 4);
+    PWSTAMP(4);
 }
 
 

@@ -70,6 +70,10 @@ def main():
     if st[2, 6, 0]:
         print("per_add_range_wg (cycles since its start): " + ", ".join(
             f"{lab} +{int(st[2, i, 0] - st[2, 6, 0])}" for lab, i in (("inner nodes stored", 7), ("barrier", 8), ("end-node chain done", 9))))
+    if st[4, 0, 1] and st[6, 0, 1]:
+        print("priority write-back inside k_dw, wave of chunk 0 (real-time us since block 0 of the same launch started): " + ", ".join(
+            f"{lab} {(int(st[4, i, 1]) - int(st[6, 0, 1])) / 100.0:.2f}" for lab, i in (("start", 0), ("ownership found", 1), ("leaf + sib loads", 2), ("levels done", 3), ("end", 4)))
+              + f"; block 0 (dW tile) ends at {(int(st[6, 3, 1]) - int(st[6, 0, 1])) / 100.0:.2f}")
     for k, (name, labels) in NAMES.items():
         t = st[k, :len(labels)]
         cyc = t[:, 0] - t[0, 0]; real = (t[:, 1] - t[0, 1]) * 10.0     # ns
