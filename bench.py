@@ -90,6 +90,11 @@ def pmc_traffic(label):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if files and label.startswith("per_sample_B"):     # the stand-alone sampler, one record per batch size
+        rec = json.load(open(files[-1])).get("k_per_sample2/" + label[len("per_sample_"):])
+        if not rec or "FETCH_SIZE_KB_per_launch_median" not in rec or "WRITE_SIZE_KB_per_launch_median" not in rec:
+            return None
+        return (rec["FETCH_SIZE_KB_per_launch_median"] * rec.get("fetch_correction", 1.0) + rec["WRITE_SIZE_KB_per_launch_median"]) * 1024.0
     if not files or label not in PMC_KEYS:
         return None
     key, corr = PMC_KEYS[label]
@@ -108,6 +113,17 @@ def pmc_traffic(label):
     if "FETCH_SIZE_KB_per_launch_median" not in rec or "WRITE_SIZE_KB_per_launch_median" not in rec:
         return None
     return (rec["FETCH_SIZE_KB_per_launch_median"] * corr + rec["WRITE_SIZE_KB_per_launch_median"]) * 1024.0
+
+
+def mfma_counters(kernel):
+    """MFMA-pipe counters of `kernel` from the committed rocprofv3 --pmc pass (profiles/r*_pmc_mfma.json), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))
+    if not files:
+        return None
+    recs = json.load(open(files[-1]))
+    hits = {k: v for k, v in recs.items() if k.split("<")[0].split("/")[0] == kernel.split(" ")[0]}
+    return hits or None
 
 
 def prefill(eng, gen):
@@ -130,10 +146,22 @@ def prefill(eng, gen):
         eng.per_set(idx, pr)
 
 
-def cpu_baseline(seconds=float(os.environ.get("DQN_BENCH_CPU_SECONDS", "12"))):
-    """The oracle's plain-C restatement (oracle/, kind "port") timed on this host, single thread, on a
-    bounded sample of the same workload: same shapes, ring 2^20, same step definition."""
-    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+def host_threads():
+    """threads the CPU legs may use: CPUs this process may run on, capped by the cgroup CPU quota (a GPU box gives one
+    GPU's share of a 256-core host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_port_world():
+    """ring 2^20 + tree filled with the bench distribution, a learner on it (the plain-C oracle; checker code only)"""
+    sys.path[:0] = [p for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")) if p not in sys.path]
     import _oracle as oc
     from _oracle import onp
     dims = (D, H1, H2, A)
@@ -149,25 +177,107 @@ def cpu_baseline(seconds=float(os.environ.get("DQN_BENCH_CPU_SECONDS", "12"))):
         per.set(slots, (np.maximum(rng.random(chunk), 1e-4) ** 0.6).astype(np.float32))
     lrn = oc.CLearner(dims, oc.Opt(2e-4, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, rb, per, onp.init_params(dims, 0), 0)
     obs = rng.standard_normal((N_ENVS, D), dtype=np.float32)
-    env_ctr = 0
+    return oc, lrn, obs
+
+
+def _time_steps(step, seconds):
+    """warm up twice, then whole steps until `seconds` have passed (at least 3): (steps, elapsed)"""
+    step(); step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(); n += 1
+        dt = time.perf_counter() - t0
+        if (dt >= seconds and n >= 3) or n >= 20000:
+            return n, dt
+
+
+def _torch_cpu_leg(seconds, threads):
+    """the same step in PyTorch-CPU (autograd + torch.optim.AdamW; SURVEY.md 8(d) "CPU-torch"): proportional PER as
+    cumsum + searchsorted over the 2^20 priorities (what a torch user would write; no sum-tree), stratified draws"""
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    N = 1 << LOG2N
+    P0 = init_params(D * H1 + H1 + H1 * H2 + H2 + H2 + 1 + H2 * A + A)
+    shapes = ((D, H1), (H1,), (H1, H2), (H2,), (H2, 1), (1,), (H2, A), (A,))
+    ps, o = [], 0
+    for sh in shapes:
+        n = int(np.prod(sh)); ps.append(P0[o:o + n].view(sh).clone().requires_grad_(True)); o += n
+    tg = [p.detach().clone() for p in ps]
+    opt = torch.optim.AdamW(ps, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+
+    def fwd(p, x):                           # LunarLander/dddqn.py:24-31
+        h = torch.relu(torch.relu(x @ p[0] + p[1]) @ p[2] + p[3])
+        v, adv = h @ p[4] + p[5], h @ p[6] + p[7]
+        return v + adv - adv.mean(1, keepdim=True)
+    S = torch.randn(N, D, generator=g); S2 = torch.randn(N, D, generator=g)
+    Aa = torch.randint(0, A, (N,), generator=g); R = torch.randn(N, generator=g); Dn = (torch.rand(N, generator=g) < P_DONE).float()
+    prio = torch.rand(N, generator=g).clamp_min(1e-4) ** 0.6
+    obs = torch.randn(N_ENVS, D, generator=g)
+    state = {"c": 0, "pmax": 1.0}
 
     def step():
-        nonlocal env_ctr
+        nonlocal obs
+        with torch.no_grad():
+            for _ in range(TRAIN_FREQ):      # q_agent.py:176-183
+                a = torch.where(torch.rand(N_ENVS, generator=g) > 0.15, fwd(ps, obs).argmax(1), torch.randint(0, A, (N_ENVS,), generator=g))
+                nxt = torch.randn(N_ENVS, D, generator=g); dn = (torch.rand(N_ENVS, generator=g) < P_DONE).float()
+                sl = (torch.arange(N_ENVS) + state["c"]) % N
+                S[sl] = obs; S2[sl] = nxt; Aa[sl] = a; R[sl] = torch.randn(N_ENVS, generator=g); Dn[sl] = dn; prio[sl] = state["pmax"]
+                state["c"] += N_ENVS; obs = nxt
+            cs = torch.cumsum(prio, 0)       # proportional PER, stratified
+            u = (torch.arange(B) + torch.rand(B, generator=g)) * (cs[-1] / B)
+            idx = torch.searchsorted(cs, u).clamp_max(N - 1)
+            w = (N * prio[idx] / cs[-1]) ** -0.4; w = w / w.max()
+            s, s2, a, r, d = S[idx], S2[idx], Aa[idx], R[idx], Dn[idx]
+            q, nq, nt = fwd(ps, s), fwd(ps, s2), fwd(tg, s2)       # q_learning_functions.py:52-60
+            delta = r + (1 - d) * (0.99 * nt.gather(1, nq.argmax(1, keepdim=True)).squeeze(1) - q.gather(1, a[:, None]).squeeze(1))
+            targets = q + delta[:, None] * torch.nn.functional.one_hot(a, A)
+        opt.zero_grad(set_to_none=True)
+        loss = (w * torch.nn.functional.huber_loss(fwd(ps, s), targets, reduction="none", delta=1.0).sum(1)).mean()   # :35-36
+        loss.backward(); opt.step()          # :23-25
+        with torch.no_grad():
+            prio[idx] = (delta.abs() + 1e-6) ** 0.6
+            state["pmax"] = max(state["pmax"], float(prio[idx].max()))
+    n, dt = _time_steps(step, seconds)
+    return {"value": n / dt, "unit": "grad-updates/sec", "cores": threads, "kind": "port",
+            "sample": f"{n} steps in {dt:.1f} s, PyTorch-CPU {torch.__version__} autograd + torch.optim.AdamW, "
+                      f"PER by cumsum + searchsorted, {threads} threads"}
+
+
+def cpu_baseline(seconds=float(os.environ.get("DQN_BENCH_CPU_SECONDS", "8"))):
+    """CPU restatements of the same step timed on this host on a BOUNDED sample (about `seconds` each):
+    the plain-C oracle on all cores this process may use (OpenMP, oracle/dqn_oracle_omp.c -- the headline `value`),
+    the same code on one thread, and a PyTorch-CPU version. kind "port": the reference's JAX path cannot run here."""
+    threads = host_threads()
+    oc, lrn, obs = _cpu_port_world()
+    env = {"c": 0}
+
+    def step_1t():
         for _ in range(TRAIN_FREQ):
-            env_ctr = lrn.actor_step(obs, 0.15, P_DONE, env_ctr)
+            env["c"] = lrn.actor_step(obs, 0.15, P_DONE, env["c"])
         lrn.update(B)
 
-    step()                                   # warm-up
-    t0 = time.perf_counter(); step(); t1 = time.perf_counter() - t0
-    n = int(min(max(seconds / max(t1, 1e-6), 3), 2000))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "grad-updates/sec", "cores": 1, "kind": "port",
-            "sample": f"{n} steps (4x256 env-steps + 1 update of B=1024 each) of the same workload in {dt:.1f} s, "
-                      f"plain-C oracle (oracle/dqn_oracle_*.c, gcc -O3 -mavx2 -mfma), 1 thread of {os.cpu_count()} host cores",
-            "env_steps_per_sec": n * N_ENVS * TRAIN_FREQ / dt}
+    def step_omp():
+        for _ in range(TRAIN_FREQ):
+            env["c"] = lrn.actor_step_omp(obs, 0.15, P_DONE, env["c"])
+        lrn.update_omp(B)
+
+    n1, dt1 = _time_steps(step_1t, seconds)
+    oc.lib().orc_omp_set_threads(threads)
+    nt_, dtt = _time_steps(step_omp, seconds)
+    what = "steps (4x256 env-steps + 1 update of B=1024 each) of the same workload"
+    out = {"value": nt_ / dtt, "unit": "grad-updates/sec", "cores": threads, "kind": "port",
+           "sample": f"{nt_} {what} in {dtt:.1f} s, plain-C oracle with OpenMP (oracle/dqn_oracle_*.c, gcc -O3 -mavx2 -mfma "
+                     f"-fopenmp; bit-identical to its 1-thread form), {threads} threads = the CPUs this process may use of "
+                     f"{os.cpu_count()} host cores",
+           "env_steps_per_sec": nt_ * N_ENVS * TRAIN_FREQ / dtt,
+           "one_thread": {"value": n1 / dt1, "unit": "grad-updates/sec", "cores": 1, "kind": "port",
+                          "sample": f"{n1} {what} in {dt1:.1f} s, the same C code on 1 thread"}}
+    try:
+        out["torch_cpu"] = _torch_cpu_leg(seconds, threads)
+    except Exception as ex:                  # noqa: BLE001 -- a baseline leg must not lose the GPU line
+        out["torch_cpu"] = {"error": repr(ex)}
+    return out
 
 
 def quick_rate(dq, precision, rank, world, steps):
@@ -211,17 +321,96 @@ def init_params(n_params):
     return P0
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher environment: start the N rank processes ourselves, as CHILDREN created
+    before this process has made any GPU call (never an exec of a process that touched the GPU), relay rank 0's single
+    JSON line and the children's exit status."""
+    import socket
+    import subprocess
+    if os.environ.get("DQN_BENCH_SPAWN_SELFTEST") != "1":
+        have = torch.cuda.device_count()                      # counts devices without initialising the GPU
+        if have < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+            return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:                                     # rank 0 prints exactly one JSON line
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        elif t:
+            print(t, file=sys.stderr)
+    rc = proc.wait()
+    if line is None:
+        print(f"[bench] the rank processes printed no result line (exit status {rc})", file=sys.stderr)
+        return rc or 4
+    print(line, flush=True)
+    return rc
+
+
+def spawn_selftest(args, json_fd):
+    """CPU rehearsal of the launcher path (tests/test_host.py): gloo ranks, no GPU work, one JSON line from rank 0"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(4) * (dist.get_rank() + 1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        os.write(json_fd, (json.dumps({"metric": "grad-updates/sec", "value": 0.0, "n_gpus": dist.get_world_size(),
+                                       "steps": args.steps, "warmup": args.warmup, "selftest": True,
+                                       "allreduce_sum": float(t[0])}) + "\n").encode())
+    dist.barrier(); dist.destroy_process_group()
+
+
+def per_sample_lines(dq, rank):
+    """the stand-alone PER-sample kernel (dqn_per_sample: stratified descent + gather) timed live with
+    HIP events at the bench shape (B = 1024: its latency floor) and at large B (its bandwidth slope); ring 2^20, D = 8"""
+    eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=16, hidden2=16, num_actions=A, capacity=1 << LOG2N, use_per=True,
+                                    max_batch=1 << 20, seed=77 + rank))
+    gen = torch.Generator(device=eng.device); gen.manual_seed(99)
+    prefill(eng, gen)
+    out = {}
+    st = eng.stream
+    with torch.cuda.stream(st):
+        for lb in (10, 16, 18, 20):
+            Bs = 1 << lb
+            bufs = eng._batch_out(Bs) + (eng.empty((Bs,), torch.int32), eng.empty((Bs,), torch.float32))
+            ms = []
+            for it in range(12):
+                eng.profile_begin(st)
+                eng.per_sample_into(Bs, 0.4, 1, it, bufs)
+                ms += [m for n, m in eng.profile_end(st) if n == "per_sample"]
+            us = float(np.median(ms[2:])) * 1e3
+            alg = (4 * LOG2N + 16 * D + 26) * Bs
+            out[f"per_sample_B{Bs}"] = {"bound": "hbm", "avg_us": us, "launches_per_step": 0, "achieved": alg / us / 1e3,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS,
+                                        "traffic": pmc_traffic(f"per_sample_B{Bs}"), "algorithmic_bytes": alg,
+                                        "note": ("latency floor at the bench batch" if lb == 10 else "sweep point (not the bench batch)")
+                                                + "; stand-alone kernel k_per_sample2 -- inside the bench step the batch is drawn by k_actor's sampler workgroups"}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=7, help="timed regions of exactly --steps steps; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=50)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary bf16 measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary bf16 measurement and the PER-sample lines")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = exact f32 MFMA (meets the 1e-5 parity bar; default); bf16 = bf16 MFMA throughput path")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                          # nothing above or inside has touched the GPU
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on communicator creation)
     # write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the line goes to the saved fd
     sys.stdout.flush()
@@ -232,12 +421,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
+    if os.environ.get("DQN_BENCH_SPAWN_SELFTEST") == "1":
+        return spawn_selftest(args, json_fd)
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    # DQN_BENCH_FORCE_DP=1: take the multi-GPU code path (two half-graphs + RCCL all-reduce on the zero-copy
-    # gradient view) even with one rank -- the only way to rehearse it on a 1-GPU box
+    # DQN_BENCH_FORCE_DP=1: take the multi-GPU code path with one rank (plumbing rehearsal on a 1-GPU box; a one-rank
+    # all-reduce moves nothing, so this says nothing about the collective itself)
     force_dp = os.environ.get("DQN_BENCH_FORCE_DP") == "1"
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -252,7 +442,6 @@ def main():
                           max_batch=B, optimizer="adamw", lr=2e-4, gamma=0.99, seed=1000 + rank, world_size=world,
                           precision=args.precision)
     eng = dq.Engine(cfg)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     gen = torch.Generator(device=eng.device); gen.manual_seed(1234 + rank)
     P0 = init_params(eng.param_count)
     eng.set_params(P0); eng.set_params(P0, L.BUF_TARGET)
@@ -269,18 +458,19 @@ def main():
     # N > 1, preferred path: the handle's own RCCL communicator, its all-reduce captured inside the inner-loop graph
     # (ITERS_PER_GRAPH iterations per launch, as on one GPU). Checked once against torch.distributed's all-reduce;
     # any failure on any rank sends every rank to the eager torch.distributed path.
-    native = False
+    native, rccl_ranks = False, None
     if dp and os.environ.get("DQN_BENCH_DP", "native") == "native":
         ok = 1
         try:
             eng.comm_init_native()
+            rccl_ranks = eng.comm_ranks()
             probe = (torch.arange(eng.param_count, device=eng.device, dtype=torch.float32) % 251) * (1.0 + rank)
             grad.copy_(probe)
             with torch.cuda.stream(st):
                 eng.allreduce_grads_native(st)
             torch.cuda.synchronize()
             want = probe.clone(); dist.all_reduce(want)
-            ok = int(torch.allclose(grad, want, rtol=1e-6, atol=0.0))
+            ok = int(torch.allclose(grad, want, rtol=1e-6, atol=0.0) and rccl_ranks == world)
         except Exception as ex:                               # noqa: BLE001 -- fall back, report below
             print(f"[bench] native RCCL path unavailable on rank {rank}: {ex}", file=sys.stderr)
             ok = 0
@@ -299,6 +489,8 @@ def main():
             flag = torch.tensor([ok], device=eng.device, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             native = bool(flag.item())
+    if dp and rccl_ranks is None:
+        rccl_ranks = dist.get_world_size()
 
     def run_steps(k):
         """exactly k steps; a step = TRAIN_FREQ vector env steps + one update"""
@@ -319,18 +511,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn):
+        """one timed region: barrier + synchronize on both sides; HIP events on the launch stream bracket the work on the
+        GPU, perf_counter the host's view; both as the MAX over ranks"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(st)
+        fn()
+        e1.record(st)
+        barrier()
+        wall = time.perf_counter() - t0
+        t = torch.tensor([e0.elapsed_time(e1) * 1e-3, wall], device=eng.device, dtype=torch.float64)
+        if dp:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), float(t[1].item())
+
     with torch.cuda.stream(st):
         run_steps(args.warmup)
         run_steps(args.steps)                                # also instantiates every graph shape used below
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], device=eng.device, dtype=torch.float64)
-        if dp:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        reps = [timed(lambda: run_steps(args.steps)) for _ in range(max(args.repeats, 1))]
+        ev = sorted(r[0] for r in reps); wl = sorted(r[1] for r in reps)
+        dt, dt_wall = ev[len(ev) // 2], wl[len(wl) // 2]
 
         # update-only and actor-only rates (same run, extra information)
         def upd_only(k):
@@ -338,17 +540,13 @@ def main():
                 for _ in range(k):
                     eng.update_backward(B, st); dist.all_reduce(grad); eng.update_apply(B, st)
             else:
-                for _ in range(k // ITERS_PER_GRAPH):
+                for _ in range(max(k // ITERS_PER_GRAPH, 1)):
                     eng.train_iters(ITERS_PER_GRAPH, 0, B, st)
         upd_only(ITERS_PER_GRAPH)
-        barrier(); t0 = time.perf_counter()
-        upd_only(args.steps)
-        barrier(); dt_upd = time.perf_counter() - t0
-        n_upd = args.steps if (dp and not native) else args.steps // ITERS_PER_GRAPH * ITERS_PER_GRAPH
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.actor_step(st)
-        barrier(); dt_act = time.perf_counter() - t0
+        n_upd = args.steps if (dp and not native) else max(args.steps // ITERS_PER_GRAPH, 1) * ITERS_PER_GRAPH
+        dt_upd = sorted(timed(lambda: upd_only(args.steps))[0] for _ in range(3))[1]
+        eng.actor_step(st)
+        dt_act = sorted(timed(lambda: [eng.actor_step(st) for _ in range(args.steps)])[0] for _ in range(3))[1]
 
         # live per-kernel timing with HIP events on the launch stream (rank 0 of N=1 is enough)
         kern = {}
@@ -363,6 +561,8 @@ def main():
                     kern.setdefault(name, []).append(ms)
     loss = float(eng.last_loss().item())
     assert np.isfinite(loss), "non-finite loss"
+    dev_err = eng.device_errors()
+    assert dev_err == 0, f"in-kernel hand-over timed out {dev_err} time(s)"
 
     if rank == 0:
         per_step = {}
@@ -397,12 +597,19 @@ def main():
                 "kernel": KERNEL_OF.get(dom, dom) + (f" (per step: {fwd_shapes}; per-shape lines under \"kernels\")" if dom == "k_qnet_fwd" else ""),
                 "avg_us": gtime[dom] / nl, "launches_per_step": nl,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r*_pmc.json, bytes per launch",
+                "mfma_counters": mfma_counters(dom),
                 "timing": "hipExtLaunchKernelGGL start/stop events of each eager launch on the launch stream, median of "
                           f"{args.profile_steps}; rocprofv3 summary of the same command in profiles/"}
         out = {
             "metric": "grad-updates/sec", "value": world * args.steps / dt, "unit": "grad-updates/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "repeats": len(reps), "min": world * args.steps / ev[-1], "max": world * args.steps / ev[0],
+            "timing": f"median of {len(reps)} timed regions of exactly {args.steps} steps each, barrier + synchronize on both "
+                      "sides, HIP events on the launch stream, MAX over ranks; host perf_counter view of the same regions "
+                      "under wall_clock",
+            "wall_clock": {"value": world * args.steps / dt_wall, "ms_per_step": dt_wall / args.steps * 1e3,
+                           "min": world * args.steps / wl[-1], "max": world * args.steps / wl[0]},
             "config": {"workload": "LunarLander-v2 shape, 256 vectorised synthetic envs, PER batch=1024, 2x256 dueling MLP "
                                    "(BASELINE.json configs[1]); step = 4 vector env steps (1024 env-steps) + 1 grad update",
                        "obs_dim": D, "num_actions": A, "hidden": [H1, H2], "batch": B, "global_batch": B * world,
@@ -410,6 +617,7 @@ def main():
                        "train_frequency": TRAIN_FREQ, "parallelism": f"dp{world} independent learners + grad all-reduce",
                        "allreduce": ("none (1 GPU)" if not dp else "RCCL, captured in the inner-loop graph" if native
                                      else "torch.distributed (RCCL), eager between two graph launches")},
+            "rccl_ranks": rccl_ranks,
             "env_steps_per_sec": world * args.steps * N_ENVS * TRAIN_FREQ / dt,
             "update_only_per_sec": world * n_upd / dt_upd,
             "actor_only_env_steps_per_sec": world * args.steps * N_ENVS / dt_act,
@@ -420,6 +628,7 @@ def main():
         if world == 1 and not dp and args.precision == "f32" and not args.no_secondary:
             eng.close()
             out["bf16"] = quick_rate(dq, "bf16", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH))
+            out["kernels"].update(per_sample_lines(dq, rank))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

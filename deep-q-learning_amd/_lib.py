@@ -13,6 +13,8 @@ OPT_ADAM, OPT_ADAMW = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
 ENV_SYNTHETIC, ENV_CARTPOLE = 0, 1
+FLAG_NO_HANDOVER, FLAG_NO_ACTOR16, FLAG_BF16_F32_ACTOR = 1, 2, 4
+ABI_VERSION = 2
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
  BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,
  BUF_ENV_ACTIONS) = range(17)
@@ -25,7 +27,7 @@ class DqnConfig(C.Structure):
                 ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("gamma", C.c_float),
                 ("per_alpha", C.c_float), ("per_eps", C.c_float), ("per_beta", C.c_float),
                 ("precision", C.c_int32), ("seed", C.c_uint64), ("world_size", C.c_int32),
-                ("n_step", C.c_int32)]
+                ("n_step", C.c_int32), ("flags", C.c_int32), ("obs_time_feature", C.c_int32)]
 
 
 _P, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -73,6 +75,8 @@ SIGNATURES = {
     "dqn_comm_unique_id": [_P],
     "dqn_comm_init": [_P, _P, _I32, _I32],
     "dqn_allreduce_grads": [_P, _P],
+    "dqn_comm_count_host": [_P, C.POINTER(_I32)],
+    "dqn_device_errors_host": [_P, C.POINTER(_I64)],
 }
 OTHER = {"dqn_last_error": ([], C.c_char_p), "dqn_abi_version": ([], C.c_int),
          "dqn_default_config": ([C.POINTER(DqnConfig)], None)}
@@ -97,6 +101,8 @@ def load():
     for name, (args, res) in OTHER.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, res
+    if lib.dqn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.dqn_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -233,8 +233,7 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
                 if (seg_n[seg] > 0) per_add_range_ends(e.tree, e.Nt, e.L, lmax, seg_a[seg], (int)seg_n[seg], pmax, lds, 256);
             BSTAMP(1);
             // every sampler workgroup has stored (and released) its share of the inner nodes?
-            if (tid == 0)
-                while (__hip_atomic_load(&e.st->fill_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nfill) __builtin_amdgcn_s_sleep(4);
+            if (tid == 0 && !wait_word_eq(&e.st->fill_cnt, (unsigned)nfill, 4)) flag_wait_timeout(e.st);   // bounded: dqn_device.h
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (e.rebuild_top) per_top_wg(e.tree, e.L, lds, 256);
@@ -266,9 +265,7 @@ __device__ __forceinline__ void actor_side_role(int role, int wg, const ActorArg
             float uu[NR];
             int tile = wg;
             if (tile < ntile) presample_draw<NR>(g.smp, tile * rows, g.B, tid, uu);
-            if (tid == 0)
-                while (__hip_atomic_load(&e.st->tree_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ticket_val)
-                    __builtin_amdgcn_s_sleep(8);                             // (hundreds of pollers of one line: poll sparsely; acquire below)
+            if (tid == 0 && !wait_word_eq(&e.st->tree_ready, ticket_val, 8)) flag_wait_timeout(e.st);   // bounded; (hundreds of pollers of one line: poll sparsely; acquire below)
             if (wg == 0) BSTAMP(5);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1172,30 +1169,36 @@ bool actor_multi_supported(const NetDims &m, int n_envs, int T) {
 // together) doubles up to 4 before a workgroup has to loop over tiles
 static void set_samplers(ActorArgs &g, int B, int cap) {
     g.NR = 1; g.n_smp = 0;
-    if (B <= 0) return;
-    if (cap > 254) cap = 254;
+    if (B <= 0 || cap < 1) return;
     while (g.NR < 4 && (B + 16 * g.NR - 1) / (16 * g.NR) > cap) g.NR *= 2;
     g.n_smp = (B + 16 * g.NR - 1) / (16 * g.NR);
     if (g.n_smp > cap) g.n_smp = cap;
 }
 
-void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
-                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16) {
+bool launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
+                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16, int num_cus, bool no_wide) {
     ActorArgs g{};
     g.env = env; g.T = T; g.params = params; g.pack = pack; g.act_out = act_out;
+    // The tree workgroup, the samplers and (through the arrival tickets) the actors of one launch wait for each other: the
+    // whole grid has to be resident. Residency comes from the grid size alone (cdna guide, Workgroups / residency):
+    // res = workgroups of this kernel a CU holds x the device's CUs, minus one CU of margin.
+    const bool want_smp = smp && env.tree && B > 0;
     // small nets (exact f32, one-step returns): 16 envs per workgroup on the 16x16x4 MFMA, all weights in registers (k_actor16)
-    const bool wide = !bf16 && env.n_step <= 1 && m.D <= 16 && m.H1 <= 128 && m.H2 <= 128 && getenv("DQN_NO_ACTOR16") == nullptr;
+    const bool wide = !bf16 && env.n_step <= 1 && m.D <= 16 && m.H1 <= 128 && m.H2 <= 128 && !no_wide;
     if (wide) {
-        // (about 110-180 registers per thread and <= 70 KB of LDS: two workgroups of this kernel share a CU, so up to 510 are
-        // resident at once -- room for one sampler workgroup per 16 batch rows up to 255 beside the actors)
+        // (about 110-180 registers per thread and <= 70 KB of LDS: two workgroups of this kernel share a CU -- room for one
+        // sampler workgroup per 16 batch rows beside the actors)
+        const int res = 2 * (num_cus - 1);
         g.n_tree = env.tree ? 1 : 0;
         g.tiles = (env.n + 15) / 16;
-        set_samplers(g, (smp && env.tree && B > 0) ? B : 0, g.tiles <= 255 ? 509 - g.tiles : 254);
-        const int room = 2 * 255 - g.n_tree - g.n_smp;
+        const int half = res / 2;                                        // at least half the machine stays with the actors' tiles
+        set_samplers(g, want_smp ? B : 0, (g.tiles <= half ? res - 1 - g.tiles : half - 1));
+        const int room = res - g.n_tree - g.n_smp;
         g.G = g.tiles < room ? g.tiles : room;
+        if (g.G < 1) { g.n_smp = 0; g.G = 1; }                           // (a device of one CU: actors loop, the tree workgroup queues behind them without anyone waiting on it)
         g.B = B;
         if (g.n_smp) g.smp = *smp;
-        const int KQ = (m.H1 <= 64 && m.H2 <= 64) ? 4 : 8;
+    const int KQ = (m.H1 <= 64 && m.H2 <= 64) ? 4 : 8;
         const int DWh = ((m.D + 3) & ~3) + 4;
         g.TC = 6144 / (16 * DWh);
         if (g.TC > T) g.TC = T;
@@ -1210,15 +1213,17 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
         const dim3 grid(g.n_tree + g.G + g.n_smp), block(256);
         if (KQ == 4) DQN_LAUNCH((k_actor16<4>), grid, block, lds, s, m, g);
         else DQN_LAUNCH((k_actor16<8>), grid, block, lds, s, m, g);
-        return;
+        return g.n_smp > 0;
     }
     // the register-resident weight slab limits a CU to ONE workgroup of this kernel, whatever its role: keep the
-    // grid within the 256 CUs so that tree, sampler and actor workgroups all run side by side
+    // grid within the device's CUs so that tree, sampler and actor workgroups all run side by side
+    const int res = num_cus - 1;
     g.n_tree = env.tree ? 1 : 0;
-    set_samplers(g, (smp && env.tree && B > 0) ? B : 0, 64);
+    set_samplers(g, want_smp ? B : 0, (res + 1) / 4 < 64 ? (res + 1) / 4 : 64);
     g.tiles = (env.n + 3) / 4;
-    const int room = 255 - g.n_tree - g.n_smp;
+    const int room = res - g.n_tree - g.n_smp;
     g.G = g.tiles < room ? g.tiles : room;
+    if (g.G < 1) { g.n_smp = 0; g.G = 1; }
     g.B = B;
     if (g.n_smp) g.smp = *smp;
     const int DP = (m.D + 3) & ~3;
@@ -1244,8 +1249,9 @@ void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
                     else DQN_LAUNCH((k_actor<K1, K2, false, true>), grid, block, lds, s, m, g); }                \
         else { if (env.n_step > 1) DQN_LAUNCH((k_actor<K1, K2, true, false>), grid, block, lds, s, m, g);        \
                else DQN_LAUNCH((k_actor<K1, K2, false, false>), grid, block, lds, s, m, g); }                    \
-        return; }
+        return g.n_smp > 0; }
     ACTOR_CASE(1, 4) ACTOR_CASE(2, 4) ACTOR_CASE(4, 4) ACTOR_CASE(8, 4) ACTOR_CASE(16, 4)
     ACTOR_CASE(1, 16) ACTOR_CASE(2, 16) ACTOR_CASE(4, 16) ACTOR_CASE(8, 16) ACTOR_CASE(16, 16)
 #undef ACTOR_CASE
+    return false;
 }

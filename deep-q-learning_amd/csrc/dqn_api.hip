@@ -42,6 +42,7 @@ extern "C" void dqn_default_config(dqn_config *c) {
     c->weight_decay = 1e-4f; c->gamma = 0.99f;
     c->per_alpha = 0.6f; c->per_eps = 1e-6f; c->per_beta = 0.4f;
     c->precision = DQN_PREC_F32; c->seed = 0; c->world_size = 1;
+    c->n_step = 1; c->flags = 0; c->obs_time_feature = 0;
 }
 
 // ------------------------------------------------------------------------------ handle
@@ -55,6 +56,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -81,11 +83,14 @@ struct dqn_handle {
     float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
     int *tile_cnt = nullptr;                                      // per-tile hand-over counters of the fused forward + row backward
+    unsigned int *wmax_tmp = nullptr;                             // batch max of the raw IS weights (API sampler -> normalise)
+    int num_cus = 256;                                            // hipDeviceAttributeMultiprocessorCount of the handle's device
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
     float *hist_s = nullptr, *hist_r = nullptr; int32_t *hist_a = nullptr, *hist_d = nullptr;   // n-step history
     int n_step = 1; float gamma_n = 0.0f;
-    bool no_fuse_rows = getenv("DQN_NO_FUSE_ROWS") != nullptr;    // diagnostic: keep k_bwd_rows as its own launch
-    bool f32_actor = getenv("DQN_BF16_F32_ACTOR") != nullptr;     // diagnostic: bf16 mode with the exact-f32 actor chain
+    bool no_handover = false;                                     // DQN_FLAG_NO_HANDOVER: no in-launch waits (no sampler workgroups, k_bwd_rows on its own)
+    bool no_actor16 = false, f32_actor = false;                   // DQN_FLAG_NO_ACTOR16 / DQN_FLAG_BF16_F32_ACTOR
+    int tile_stride = 0;                                          // tile_cnt: [tile_stride] arrival counters + [tile_stride] consumed counts
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
@@ -111,8 +116,8 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
 }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
                   const BwdArgs *fuse = nullptr) {
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st);
-    else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st);
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
+    else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -152,15 +157,24 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
     REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
     REQUIRE(cfg->n_step >= 0 && cfg->n_step <= 8, "n_step %d out of range [0,8]", cfg->n_step);
+    REQUIRE((cfg->flags & ~7) == 0, "unknown flags 0x%x", cfg->flags);
     REQUIRE(cfg->n_step <= 1 || cfg->capacity >= 64ll * cfg->max_batch, "n_step > 1 needs capacity >= 64 * max_batch "
             "(the n-step actor runs in k_actor only, whose steps of one launch must fit the ring)");
 
     dqn_handle *h = new (std::nothrow) dqn_handle();
     if (!h) return fail(DQN_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
+    {   // machine size: every grid that must be resident as a whole is derived from it
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->num_cus = cus;
+    }
     h->m = make_dims(D, H1, H2, A);
     h->world = cfg->world_size;
     h->bf16 = cfg->precision == DQN_PREC_BF16;
+    h->no_handover = (cfg->flags & DQN_FLAG_NO_HANDOVER) != 0;
+    h->no_actor16 = (cfg->flags & DQN_FLAG_NO_ACTOR16) != 0;
+    h->f32_actor = (cfg->flags & DQN_FLAG_BF16_F32_ACTOR) != 0;
     h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
     h->gamma_n = cfg->gamma;
     for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
@@ -196,7 +210,8 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
-    add(&h->tile_cnt, (Bp / 16) * 4);
+    h->tile_stride = (int)(Bp / 16) + 2;
+    add(&h->tile_cnt, (size_t)h->tile_stride * 2 * 4); add(&h->wmax_tmp, 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
     add(&h->env_a, Bp * 4, DQN_BUF_ENV_ACTIONS); add(&h->env_d, Bp); add(&h->env_t, Bp * 4);
     if (h->n_step > 1) {
@@ -361,9 +376,12 @@ extern "C" int dqn_per_sample(dqn_handle *h, int32_t B, float beta, uint64_t see
     if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "dqn_per_sample on a handle created with use_per=0");
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(h->wmax_tmp, 0, 4, st));
+    arm(h);
     launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
-                      h->dones, h->cfg.obs_dim, B, beta, seed, ctr, 0, s, a, r, s2, d, idx, h->bw_raw);
-    launch_isw_normalize(st, h->bw_raw, B, isw, h->st);
+                      h->dones, h->cfg.obs_dim, B, beta, seed, ctr, 0, s, a, r, s2, d, idx, h->bw_raw, h->wmax_tmp, h->num_cus);
+    mark(h, st, "per_sample");
+    launch_isw_normalize(st, h->bw_raw, B, isw, h->st, h->wmax_tmp);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -533,7 +551,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     // whole grid resident (3 * tiles <= 256 workgroups) and the batch weights final before the launch (drawn by the
     // actor launch, or uniform replay): the row backward rides in the forward launch (pass-0 workgroups go on with it)
     const int grid_tiles = h->bf16 ? 2 * ((B + 31) / 32) : (B + 15) / 16;
-    const bool fuse_rows = 3 * grid_tiles <= 256 && (presampled || !h->cfg.use_per) && !h->no_fuse_rows;
+    const bool fuse_rows = 3 * grid_tiles <= h->num_cus && (presampled || !h->cfg.use_per) && !h->no_handover;
     arm(h);
     L_fwd(h, st, p, 3, B, &sm, fuse_rows ? &g : nullptr);
     mark(h, st, fuse_rows ? "sample_fwd_x3_bwd" : "sample_fwd_x3");
@@ -593,7 +611,7 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
 static bool actor_multi_ok(dqn_handle *h, int n_envs, int T) {
     return T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
 }
-static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
+static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
     const EnvArgs e = env_args(h, n_envs, rebuild_top);
     SampleArgs sm{};
     sm.st = h->st; sm.tree = h->tree; sm.N = h->Ntree; sm.L = h->L; sm.seed = h->cfg.seed;
@@ -601,9 +619,11 @@ static void enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
     arm(h);
     // bf16 mode: the same kernel on v_mfma_f32_4x4x4_16b_bf16 (weights / activations rounded to bf16 in registers from
     // the f32 shadows in pack_act: chains a quarter as long)
-    launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a, (h->cfg.use_per ? presample_B : 0), &sm,
-                       h->bf16 && !h->f32_actor);
+    const bool pre = launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a,
+                                        (h->cfg.use_per && !h->no_handover ? presample_B : 0), &sm, h->bf16 && !h->f32_actor,
+                                        h->num_cus, h->no_actor16);
     mark(h, st, "actor_steps");
+    return pre;                                                    // the PER batch of the next update is drawn
 }
 
 // q_agent.py:176-183 for n_envs device-resident envs, one vector step: k_actor with T = 1 (forward + epsilon-greedy policy +
@@ -612,9 +632,11 @@ static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuil
     enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0);
 }
 
-// capture `body` into an executable graph on the caller's stream (non-null streams only)
+// capture `body` into an executable graph on the caller's stream (non-null streams only). body_err: set non-zero by a body
+// whose capture must not be kept (a collective that failed to enqueue): the graph is dropped -- never cached, never
+// launched -- so that no later call replays an update without its all-reduce.
 template <class F>
-static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F body) {
+static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F body, const int *body_err = nullptr) {
     if (!st || h->profiling) { body(); HIP_TRY(hipGetLastError()); return DQN_OK; }   // default stream / profiling: eager
     if (!*slot) {
         hipGraph_t graph = nullptr;
@@ -622,12 +644,12 @@ static int run_captured(dqn_handle *h, hipGraphExec_t *slot, hipStream_t st, F b
         body();
         hipError_t e = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess) return fail(DQN_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        if (body_err && *body_err) { (void)hipGraphDestroy(graph); return DQN_ERR_COMM; }
         e = hipGraphInstantiate(slot, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { *slot = nullptr; return fail(DQN_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
     }
     HIP_TRY(hipGraphLaunch(*slot, st));
-    (void)h;
     return DQN_OK;
 }
 
@@ -677,6 +699,7 @@ extern "C" int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream) {
 extern "C" int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream) {
     REQUIRE(h && obs, "null argument");
     REQUIRE(n_envs >= 1 && n_envs <= h->cfg.max_batch, "n_envs=%d exceeds max_batch=%d", n_envs, h->cfg.max_batch);
+    if (p_done != h->p_done) destroy_graphs(h);                   // p_done is a by-value argument of captured launches
     h->p_done = p_done;
     HIP_TRY(hipMemsetAsync(h->env_t, 0, (size_t)n_envs * 4, (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(&h->st->hist_steps, 0, sizeof(unsigned long long), (hipStream_t)stream));   // n-step history restarts
@@ -736,8 +759,8 @@ extern "C" int dqn_actor_backward(dqn_handle *h, int32_t env_steps, int32_t n_en
     const std::vector<int> key{-1, env_steps, n_envs, B};
     return run_captured(h, &h->loop_graphs[key], st, [&] {
         if (env_steps > 0 && actor_multi_ok(h, n_envs, env_steps)) {
-            enqueue_actor_multi(h, env_steps, n_envs, st, false, B);
-            enqueue_backward(h, B, st, false, true, false, h->cfg.use_per != 0);
+            const bool pre = enqueue_actor_multi(h, env_steps, n_envs, st, false, B);
+            enqueue_backward(h, B, st, false, true, false, pre);
             return;
         }
         for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st);
@@ -783,8 +806,8 @@ extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps
             // the env_steps actor steps of an iteration are ONE launch, which also inserts their leaves and draws the
             // update's PER batch on side workgroups
             for (int it = 0; it < n_iters; ++it) {
-                enqueue_actor_multi(h, env_steps, n_envs, st, can_defer && it > 0, B);
-                update(can_defer && it + 1 < n_iters, h->cfg.use_per != 0);
+                const bool pre = enqueue_actor_multi(h, env_steps, n_envs, st, can_defer && it > 0, B);
+                update(can_defer && it + 1 < n_iters, pre);
             }
             return;
         }
@@ -793,7 +816,7 @@ extern "C" int dqn_train_iters(dqn_handle *h, int32_t n_iters, int32_t env_steps
             for (int e = 0; e < env_steps; ++e) enqueue_actor(h, n_envs, st, can_defer && it > 0 && e == 0);
             update(can_defer && it + 1 < n_iters, false);
         }
-    });
+    }, &comm_err);
     if (comm_err) return fail(DQN_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(comm_err) : "?");
     return rc;
 }
@@ -841,6 +864,7 @@ static int load_rccl() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
         return fail(DQN_ERR_COMM, "librccl.so lacks a required symbol");
@@ -876,5 +900,26 @@ extern "C" int dqn_allreduce_grads(dqn_handle *h, void *stream) {
     const int e = g_rccl.AllReduce(h->grad, h->grad, (size_t)h->m.P, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm,
                                    (hipStream_t)stream);
     if (e) return fail(DQN_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}
+
+extern "C" int dqn_comm_count_host(dqn_handle *h, int32_t *ranks) {
+    REQUIRE(h && ranks, "null argument");
+    *ranks = 0;
+    if (!h->comm) return DQN_OK;
+    if (!g_rccl.CommCount) return fail(DQN_ERR_COMM, "librccl.so lacks ncclCommCount");
+    int n = 0;
+    const int e = g_rccl.CommCount(h->comm, &n);
+    if (e) return fail(DQN_ERR_COMM, "ncclCommCount: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    *ranks = n;
+    return DQN_OK;
+}
+
+extern "C" int dqn_device_errors_host(dqn_handle *h, int64_t *count) {
+    REQUIRE(h && count, "null argument");
+    unsigned int c = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&c, &h->st->err_count, 4, hipMemcpyDeviceToHost));
+    *count = (int64_t)c;
     return DQN_OK;
 }

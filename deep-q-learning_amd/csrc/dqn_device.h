@@ -32,12 +32,33 @@ struct DqnState {
     unsigned long long ep_count;       // finished episodes of the device-resident envs (CartPole)
     unsigned long long ep_steps;       // env steps (= return, reward 1 per step) summed over finished episodes
     unsigned long long hist_steps;     // vector env steps filed in the n-step history since dqn_env_reset
+    unsigned int       err_count;      // in-kernel hand-over waits that gave up (bounded spins; dqn_device_errors_host). While it is
+                                       // non-zero every loss written is NaN: a timed-out launch has computed on incomplete data
+    unsigned int       pad1;
     // cross-workgroup hand-overs of an actor launch, each on its own 128-B line (hundreds of workgroups poll / bump them):
     alignas(128) unsigned long long tree_ready;   // env step counter up to which the leaves are in the tree: released by the
                                        // tree workgroup, awaited by the sampler workgroups (dqn_actor.hip)
     alignas(128) unsigned int fill_cnt;           // sampler workgroups that have stored their share of the new leaves' inner
                                        // nodes (reset by the launch's commit)
 };
+
+// Bounded wait of the in-launch hand-overs (one lane polls one word): gives up after DQN_WAIT_TICKS of the 100 MHz
+// constant clock (0.2 s; the waits themselves last microseconds) so that a launch whose partner workgroups are not
+// resident -- a partitioned or shared device -- ends with an error count instead of hanging the GPU.
+#define DQN_WAIT_TICKS 20000000ull
+template <class T>
+__device__ __forceinline__ bool wait_word_eq(const T *word, T want, int sleep) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
+            if (sleep >= 8) __builtin_amdgcn_s_sleep(8); else if (sleep >= 4) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(2);
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > DQN_WAIT_TICKS) return false;
+    }
+}
+__device__ __forceinline__ void flag_wait_timeout(DqnState *st) { atomicAdd(&st->err_count, 1u); }
 
 enum { DQN_STREAM_PER = 0, DQN_STREAM_UNIFORM = 1, DQN_STREAM_POLICY = 2, DQN_STREAM_ENV = 3 };
 

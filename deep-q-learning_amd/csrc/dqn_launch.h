@@ -69,7 +69,7 @@ struct BwdArgs {
     float *loss_part;                  // [ceil(B/16)]
 };
 
-struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; };   // row backward fused into the forward launch (k_qnet_fwd<.., FUSE>)
+struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; int tiles; };   // tile_cnt: [tiles] arrival counters + [tiles] consumed counts   // row backward fused into the forward launch (k_qnet_fwd<.., FUSE>)
 
 struct PwArgs {             // sorted PER write-back run by surplus workgroups of k_dw when tree != NULL
     float *tree; long long N; int L; const int32_t *idx; const float *td_abs; int B; float alpha, eps;
@@ -84,11 +84,15 @@ void launch_pack_w2k16(hipStream_t s, const NetDims &m, const float *params, flo
 // fuse != NULL (f32, three passes, 3 * ceil(B/16) <= 256, batch weights final before the launch): the pass-0 workgroups
 // also run the row backward of their tiles (k_bwd_rows' work); tile_cnt = ceil(B/16) zeroed counters
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
-                     const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
-// T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip
+                     const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0);
+// T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip.
+// num_cus: the device's CU count -- tree, sampler and actor workgroups wait for each other inside the launch, so the grid
+// is sized to be resident as a whole; no_wide: never the 16-env small-net kernel (diagnostic). Returns whether the PER
+// batch of B rows was drawn by the launch (false: B == 0, no tree, or no room for sampler workgroups on this device --
+// the update that follows then samples for itself).
 bool actor_multi_supported(const NetDims &m, int n_envs, int T);
-void launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
-                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16 = false);
+bool launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int T, const float *params, const float *pack,
+                        int32_t *act_out, int B, const SampleArgs *smp, bool bf16, int num_cus, bool no_wide);
 void launch_td(hipStream_t s, const float *q, const float *nq, const float *nt, const int32_t *a,
                const float *r, const float *d, const float *isw, float gamma, int B, int A,
                float *targets, float *td, float *dq, float *loss, float *scratch);
@@ -120,11 +124,12 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        const float *states, const int32_t *actions, const float *rewards,
                        const float *observations, const uint8_t *dones, int D, int B, float beta,
                        unsigned long long seed, unsigned long long ctr, int from_state,
-                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw);
+                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw,
+                       unsigned int *wmax_bits, int num_cus);
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
                              const float *val, int B, int mode, float alpha, float eps);
 void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap);
-void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st);
+void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st, const unsigned int *wmax_bits);
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
                       int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,
                       long long ring_capacity);
@@ -133,7 +138,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
-                          const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr);
+                          const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

@@ -483,7 +483,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
             // passes 1, 2: the Q rows above were L1-bypassing stores of wave 0; drain them, then count this pass in
             if (wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (tid == 0) atomicAdd(&fb.tile_cnt[tile], 1);
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, 1u);
             }
             return;
         }
@@ -499,13 +499,14 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         if (rowt && g.w_raw) { wi = g.w_raw[irow]; wmax = fb.st->wmax; }
         for (int t = tid; t < 16 * s3; t += 256) l3[t] = 0.0f;
         if (tid == 0) {
-            // bounded wait (~0.3 s): the launcher only fuses grids that are resident as a whole, so the partners are
-            // running; should that ever not hold, the kernel still ends and the loss turns NaN instead of the GPU hanging
-            int spins = 0;
-            while (__hip_atomic_load(&fb.tile_cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2 && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(2);
-            if (spins >= (1 << 22)) g.loss_part[tile] = __int_as_float(0x7fc00000);
-            __hip_atomic_store(&fb.tile_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+            // bounded wait (dqn_device.h): the launcher only fuses grids that are resident as a whole, so the partners are
+            // running; should that ever not hold, the kernel still ends, the loss turns NaN and the error count goes up
+            // instead of the GPU hanging. The counter only grows (2 per launch, wrapping); the tile's pass-0 workgroup keeps
+            // what it has already consumed in seen[]: a late partner of a timed-out launch can never satisfy a later wait.
+            unsigned *cnt = reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, *seen = reinterpret_cast<unsigned *>(fb.tile_cnt) + fb.tiles + tile;
+            const unsigned want = *seen + 2u;
+            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); if (true) g.loss_part[tile] = __int_as_float(0x7fc00000); }
+            *seen = want;
         }
         LDS_BARRIER();                                               // partners' rows are in L2; l3 is zeroed
         STAMP(0, 7);
@@ -614,7 +615,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
 
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
-                     const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
+                     const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride) {
     FwdPasses ps{};
     for (int i = 0; i < npass; ++i) ps.p[i] = passes[i];
     const SampleArgs sa = smp ? *smp : SampleArgs{};
@@ -622,7 +623,7 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
     size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 32 + 528);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
-        FuseBwd fb{*fuse, tile_cnt, st};
+        FuseBwd fb{*fuse, tile_cnt, st, tile_stride};
         lds += sizeof(float) * (16 * (m.H2 + 4) + 16);
 #define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, true>), grid, block, lds, s, m, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
@@ -1044,7 +1045,8 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
         for (int t = lane; t < KQb; t += 64) s = s + loss_part[t];
         for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
         if (lane == 0) {
-            const float Lv = __fdiv_rn(s, (float)B);
+            float Lv = __fdiv_rn(s, (float)B);
+            if (st->err_count != 0u) Lv = __int_as_float(0x7fc00000);     // a hand-over wait gave up: dqn_device_errors_host
             st->loss = Lv;
             if (loss_out) *loss_out = Lv;
             if (bump_ctr) { st->sample_ctr += 1ull; st->wmax = 0.0f; }

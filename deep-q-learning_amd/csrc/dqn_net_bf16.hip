@@ -340,7 +340,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         if (blockIdx.y != 0) {
             if (wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the Q rows above have left this CU
-                if (tid == 0) atomicAdd(&fb.tile_cnt[tile], 1);
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, 1u);
             }
             return;
         }
@@ -359,11 +359,14 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         for (int t = tid; t < 16 * s3; t += 256) l3[t] = (__bf16)0.0f;
         for (int t = tid; t < 16 * (KH - m.H2); t += 256) lz2[(t / (KH - m.H2)) * s2 + m.H2 + t % (KH - m.H2)] = (__bf16)0.0f;
         if (tid == 0) {
-            int spins = 0;                                           // bounded wait: see k_qnet_fwd
-            while (__hip_atomic_load(&fb.tile_cnt[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2 && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(2);
-            if (spins >= (1 << 22) && tile < (B + 15) / 16) g.loss_part[tile] = __int_as_float(0x7fc00000);
-            __hip_atomic_store(&fb.tile_cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // bounded wait (dqn_device.h): the launcher only fuses grids that are resident as a whole, so the partners are
+            // running; should that ever not hold, the kernel still ends, the loss turns NaN and the error count goes up
+            // instead of the GPU hanging. The counter only grows (2 per launch, wrapping); the tile's pass-0 workgroup keeps
+            // what it has already consumed in seen[]: a late partner of a timed-out launch can never satisfy a later wait.
+            unsigned *cnt = reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, *seen = reinterpret_cast<unsigned *>(fb.tile_cnt) + fb.tiles + tile;
+            const unsigned want = *seen + 2u;
+            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); if (true && tile < (B + 15) / 16) g.loss_part[tile] = __int_as_float(0x7fc00000); }
+            *seen = want;
         }
         LDS_BARRIER();
         if (tid < 16) {
@@ -467,7 +470,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
 static inline int tiles16(int B) { return 2 * ((B + 31) / 32); }
 
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
-                          const BwdArgs *fuse, int *tile_cnt, DqnState *st) {
+                          const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride) {
     FwdPasses16 ps{};
     bool stash = false;
     for (int i = 0; i < npass; ++i) { ps.p[i] = passes[i]; stash |= passes[i].px != nullptr; }
@@ -477,7 +480,7 @@ void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes
     size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 32 + 528);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
-        const FuseBwd fb{*fuse, tile_cnt, st};
+        const FuseBwd fb{*fuse, tile_cnt, st, tile_stride};
         lds += 2 * 16 * (d.KQH * 32 + 8) + 4 * 16;
 #define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, true>), grid, block, lds, s, m, d, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)
@@ -745,7 +748,8 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
         for (int t = lane; t < (B + 15) / 16; t += 64) s = s + loss_part[t];
         for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
         if (lane == 0) {
-            const float Lv = __fdiv_rn(s, (float)B);
+            float Lv = __fdiv_rn(s, (float)B);
+            if (st->err_count != 0u) Lv = __int_as_float(0x7fc00000);     // a hand-over wait gave up: dqn_device_errors_host
             st->loss = Lv;
             if (loss_out) *loss_out = Lv;
             if (bump_ctr) { st->sample_ctr += 1ull; st->wmax = 0.0f; }

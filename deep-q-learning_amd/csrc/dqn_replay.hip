@@ -92,62 +92,186 @@ k_sample_uniform(const DqnState *st, const float *states, const int32_t *actions
 }
 
 // ------------------------------------------------------------------ PER sampling
-// Stratified proportional sampling: u_k = (k + U_k) * total / B, binary descent
+// Stratified proportional sampling (SURVEY.md 8(c2)): u_k = (k + U_k) * total / B, binary descent
 //   k=1; while k<N: l=tree[2k]; if u<l: k=2k else: u-=l; k=2k+1
-// clamp to < size, raw IS weight (size*p/total)^-beta via pow_det. One thread per sample.
-// ctr_from_state: take the Philox counter / beta from the device state (graph replay).
-__global__ void __launch_bounds__(256)
-k_per_sample(const DqnState *st, const float *__restrict__ tree, long long N, int L,
-             const float *states, const int32_t *actions, const float *rewards,
-             const float *observations, const uint8_t *dones, int D, int B, float beta_arg,
-             unsigned long long seed, unsigned long long ctr_arg, int from_state,
-             float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw) {
-    const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = k0 < B;
-    const int k = in_range ? k0 : B - 1;               // surplus lanes redo the last sample (no stores below)
+// clamp to < size, raw IS weight (size*p/total)^-beta via pow_det, then the five gathers of sample_batch
+// (General/Base/replay_buffer.py:78-84). Same compares / subtractions in the same order as the CPU restatement, so
+// indices, weights and rows are bit-identical; only WHERE the tree nodes are read from differs:
+//
+//   * u_k is non-decreasing in k and the descent keeps order, so the 64 samples of a wave visit, at every level, a
+//     CONTIGUOUS run of nodes [node(lane 0), node(lane 63)]. A wave therefore never chases pointers through HBM:
+//   * levels 0 .. TL-1 come from an LDS image of the tree top (depths 0 .. TL, 2^(TL+1) floats, staged once per
+//     workgroup by coalesced 16-B loads and shared by its waves over all their chunks);
+//   * below, the wave fetches its band -- the children of its run for the next t levels, one coalesced 8-B-per-lane
+//     load per level -- into a private LDS slice and walks t levels there (t = as many levels as fit PS_BAND floats:
+//     with B ~ N the whole rest of the tree in ONE round trip);
+//   * when the run gets wider than PS_WIDE nodes (B << N: every sample is alone in its subtree and a band would be
+//     mostly unused bytes) the lanes finish with one dependent 4-B load per level, as the scalar descent does;
+//   * rows are gathered lane-cooperatively: a row of D floats is D/4 16-byte pieces, consecutive lanes take consecutive
+//     pieces, so both the ring reads (sorted leaves: neighbouring rows) and the batch writes are full-width.
+// One wave = one 64-sample chunk at a time; a workgroup walks a contiguous range of chunks (persistent grid).
+// ctr_from_state: take the Philox counter / beta from the device state (graph replay) and publish the batch max there.
+#define PS_BAND 1024         // floats of LDS per wave for a band
+#define PS_WIDE 256          // run width beyond which a band costs more bytes than per-lane loads
+#define PS_TOPL 13           // deepest level walked in the shared LDS image (64 KiB)
+
+struct PerSampleArgs {
+    const DqnState *st; const float *tree; long long N; int L;
+    const float *states; const int32_t *actions; const float *rewards; const float *observations; const uint8_t *dones;
+    int D, B; float beta; unsigned long long seed, ctr; int from_state;
+    float *s; int32_t *a; float *r; float *s2; uint8_t *d; int32_t *idx; float *w_raw;
+    unsigned int *wmax_bits;     // batch max of the raw weights (positive floats order like their bit patterns)
+    int TL;                      // levels walked in the LDS image (0: none)
+    int chunks_per_wg;
+};
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+k_per_sample2(const PerSampleArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float ps_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TL = p.TL, L = p.L, B = p.B, D = p.D;
+    float *top = ps_lds;                                             // nodes [0, 2^(TL+1)) (index 0 unused)
+    float *band = ps_lds + (TL > 0 ? (2 << TL) : 0) + wave * PS_BAND;
+    int *lidx = reinterpret_cast<int *>(band);                       // the wave's 64 leaves (after the descent)
+    const float *tree = p.tree;
     STAMP(3, 0);
-    const unsigned long long ctr = from_state ? st->sample_ctr : ctr_arg;
-    const float beta = from_state ? st->beta : beta_arg;
-    const long long size = st->size;
+    if (TL > 0) {                                                    // stage the top image
+        const float4 *src = reinterpret_cast<const float4 *>(tree);
+        float4 *dst = reinterpret_cast<float4 *>(top);
+        for (int q = tid; q < (2 << TL) / 4; q += WAVES * 64) dst[q] = src[q];
+    }
+    const unsigned long long ctr = p.from_state ? p.st->sample_ctr : p.ctr;
+    const float beta = p.from_state ? p.st->beta : p.beta;
+    const long long size = p.st->size;
     const float total = tree[1];
     const float seg = __fdiv_rn(total, (float)B);
-    const u32x4 o = philox_draw(seed, ctr, (uint32_t)k, DQN_STREAM_PER);
-    float u = ((float)k + u01(o.x)) * seg;
-    long long node = 1;
-    for (int lvl = 0; lvl < L; ++lvl) {
-        const float l = tree[2 * node];
-        if (u < l) { node = 2 * node; }
-        else { u = u - l; node = 2 * node + 1; }
-    }
+    if (TL > 0) __syncthreads();
     STAMP(3, 1);
-    long long leaf = node - N;
-    if (leaf >= size) leaf = size - 1;
-    if (in_range) idx[k] = (int32_t)leaf;
-    const float p = tree[N + leaf];
-    const float w = pow_det(__fdiv_rn((float)size * p, total), -beta);
-    if (in_range) w_raw[k] = w;
-    if (from_state) {                                  // fused path: batch max for the consumer kernel
-        float mx = w;
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(const_cast<float *>(&st->wmax)), __float_as_uint(mx));
+    const int nchunks = (B + 63) >> 6;
+    const int c_begin = blockIdx.x * p.chunks_per_wg;
+    int c_end = c_begin + p.chunks_per_wg; if (c_end > nchunks) c_end = nchunks;
+    float wmx = 0.0f;
+    for (int c = c_begin + wave; c < c_end; c += WAVES) {
+        const int k0 = c << 6, k = k0 + lane;
+        const bool in_range = k < B;
+        const int kk = in_range ? k : B - 1;                         // surplus lanes redo the last sample (no stores below)
+        const u32x4 o = philox_draw(p.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
+        float u = ((float)kk + u01(o.x)) * seg;
+        unsigned node = 1;                                           // node ids < 2^31 (capacity <= 2^30)
+        for (int lvl = 0; lvl < TL; ++lvl) {
+            const float l = top[2 * node];
+            if (u < l) { node = 2 * node; }
+            else { u = u - l; node = 2 * node + 1; }
+        }
+        int lvl = TL;
+        float pleaf = 0.0f; bool have_p = false;                     // tree[node] of the final node, when it came from LDS
+        if (TL > 0 && lvl == L) { pleaf = top[node]; have_p = true; }
+        while (lvl < L) {
+            const unsigned nf = __builtin_amdgcn_readfirstlane(node), nl = __builtin_amdgcn_readlane(node, 63);
+            const int w = (int)(nl - nf) + 1;
+            if (w > PS_WIDE) break;
+            int t = 0;                                               // levels this round: w * (2^(t+1) - 2) <= PS_BAND
+            while (t < L - lvl && (long long)w * ((4ll << t) - 2) <= PS_BAND) ++t;
+            if (t == 0) break;
+            // level lvl+j of the band: nodes [nf << j, (nl + 1) << j), stored from float offset w * (2^j - 2). As 8-byte
+            // pieces the t levels are one flat run of w * (2^t - 1) <= PS_BAND / 2 pieces: piece q lies in level
+            // j = 1 + floor(log2(q / w + 1)) and is tree2[(nf << (j-1)) + q - w * (2^(j-1) - 1)]. Eight pieces per lane,
+            // every load issued before the first LDS store (clamped index instead of a branch around the load).
+            {
+                const int total2 = w * ((1 << t) - 1);
+                const float rw = __frcp_rn((float)w);                // (q + 0.5) / w is never within 1/(2w) of an integer
+                const float2 *tree2 = reinterpret_cast<const float2 *>(tree);
+                float2 *band2 = reinterpret_cast<float2 *>(band);
+                float2 pc[PS_BAND / 128];
+#pragma unroll
+                for (int i = 0; i < PS_BAND / 128; ++i) {
+                    const int q0 = lane + 64 * i, q = q0 < total2 ? q0 : total2 - 1;
+                    const int x = (int)(((float)q + 0.5f) * rw);
+                    const int jm1 = 31 - __clz(x + 1);                // j - 1
+                    pc[i] = tree2[((unsigned long long)nf << jm1) + (unsigned)(q - w * ((1 << jm1) - 1))];
+                }
+#pragma unroll
+                for (int i = 0; i < PS_BAND / 128; ++i) {
+                    const int q0 = lane + 64 * i;
+                    if (q0 < total2) band2[q0] = pc[i];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: LDS program order suffices
+            const bool to_leaf = lvl + t == L;
+            for (int j = 1; j <= t; ++j) {
+                const int at = w * ((1 << j) - 2) + (int)(2u * node - (nf << j));   // slot of the left child
+                const float l = band[at];
+                if (u < l) { node = 2 * node; if (to_leaf && j == t) pleaf = l; }
+                else { u = u - l; node = 2 * node + 1; if (to_leaf && j == t) pleaf = band[at + 1]; }
+            }
+            lvl += t;
+            have_p = to_leaf;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the band slice is rewritten next round / by lidx
+        }
+        for (; lvl < L; ++lvl) {                                     // sparse regime: per-lane dependent loads
+            const float l = tree[2ull * node];
+            if (u < l) { node = 2 * node; }
+            else { u = u - l; node = 2 * node + 1; }
+        }
+        long long leaf = (long long)node - p.N;
+        if (leaf >= size) { leaf = size - 1; have_p = false; }
+        if (!have_p) pleaf = tree[p.N + leaf];
+        const float w_is = pow_det(__fdiv_rn((float)size * pleaf, total), -beta);
+        wmx = fmaxf(wmx, w_is);
+        lidx[lane] = (int)leaf;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- the five gathers (replay_buffer.py:78-84): every load first, then the stores
+        const int nrow = (B - k0) < 64 ? (B - k0) : 64;
+        const int32_t av = p.actions[leaf]; const float rv = p.rewards[leaf]; const uint8_t dv = p.dones[leaf];
+        if (D == 8) {
+            // a row = two 16-byte pieces; lane q handles pieces q and q + 64 of the chunk's 128 (all 64 leaves are valid rows)
+            const float4 *S4 = reinterpret_cast<const float4 *>(p.states), *O4 = reinterpret_cast<const float4 *>(p.observations);
+            float4 *s4 = reinterpret_cast<float4 *>(p.s) + (long long)k0 * 2, *o4 = reinterpret_cast<float4 *>(p.s2) + (long long)k0 * 2;
+            const long long src0 = (long long)lidx[lane >> 1] * 2 + (lane & 1), src1 = (long long)lidx[32 + (lane >> 1)] * 2 + (lane & 1);
+            const float4 a0 = S4[src0], b0 = O4[src0], a1 = S4[src1], b1 = O4[src1];
+            if (lane < 2 * nrow) { s4[lane] = a0; o4[lane] = b0; }
+            if (lane + 64 < 2 * nrow) { s4[lane + 64] = a1; o4[lane + 64] = b1; }
+        } else if ((D & 3) == 0) {
+            const int C = D >> 2, tot = nrow * C;                    // 16-byte pieces of this chunk's rows
+            const float4 *S4 = reinterpret_cast<const float4 *>(p.states), *O4 = reinterpret_cast<const float4 *>(p.observations);
+            float4 *s4 = reinterpret_cast<float4 *>(p.s) + (long long)k0 * C, *o4 = reinterpret_cast<float4 *>(p.s2) + (long long)k0 * C;
+            for (int q = lane; q < tot; q += 64) {
+                const int smp = q / C, part = q - smp * C;
+                const long long src = (long long)lidx[smp] * C + part;
+                const float4 a4 = S4[src], b4 = O4[src];
+                s4[q] = a4; o4[q] = b4;
+            }
+        } else {
+            const int tot = nrow * D;
+            float *s1 = p.s + (long long)k0 * D, *o1 = p.s2 + (long long)k0 * D;
+            for (int q = lane; q < tot; q += 64) {
+                const int smp = q / D, e = q - smp * D;
+                const long long src = (long long)lidx[smp] * D + e;
+                const float x0 = p.states[src], x1 = p.observations[src];
+                s1[q] = x0; o1[q] = x1;
+            }
+        }
+        if (in_range) { p.idx[k] = (int32_t)leaf; p.w_raw[k] = w_is; p.a[k] = av; p.r[k] = rv; p.d[k] = dv; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // lidx is band space of the next chunk
     }
-    if (in_range) gather_row(states, actions, rewards, observations, dones, D, leaf, k, s, a, r, s2, d);
     STAMP(3, 2);
+    // batch max of the raw weights: one atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+    if (WAVES > 1) {
+        __syncthreads();
+        if (lane == 0) ps_lds[wave] = wmx;
+        __syncthreads();
+        if (tid == 0) for (int q = 1; q < WAVES; ++q) wmx = fmaxf(wmx, ps_lds[q]);
+    }
+    if (tid == 0 && wmx > 0.0f) atomicMax(p.wmax_bits, __float_as_uint(wmx));
 }
 
-// isw[k] = w_raw[k] / max_j w_raw[j]; every block recomputes the (order-independent) max.
+// isw[k] = w_raw[k] / max_j w_raw[j] (the max was gathered by the sampler's workgroups); st->wmax = that max
 __global__ void __launch_bounds__(256)
-k_isw_normalize(const float *__restrict__ w_raw, int B, float *isw, DqnState *st) {
-    __shared__ float red[256];
-    float m = 0.0f;
-    for (int j = threadIdx.x; j < B; j += blockDim.x) m = fmaxf(m, w_raw[j]);
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) {
-        if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
-        __syncthreads();
-    }
-    const float wmax = red[0];
+k_isw_normalize(const float *__restrict__ w_raw, int B, float *isw, DqnState *st, const unsigned int *wmax_bits) {
+    const float wmax = __uint_as_float(*wmax_bits);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < B) isw[k] = __fdiv_rn(w_raw[k], wmax);
     if (k == 0) st->wmax = wmax;
@@ -475,17 +599,34 @@ void launch_sample_uniform(hipStream_t st_, const DqnState *st, const float *sta
                        rewards, observations, dones, D, B, seed, ctr, from_state, idx_in, s, a, r, s2, d, idx_out);
 }
 
+// grid / LDS choice of k_per_sample2: many chunks -> 16-wave workgroups (one per CU, persistent over their chunk range) that
+// share a 2^(TL+1)-float image of the tree top; few chunks -> one-wave workgroups spread over the CUs, no image (the band
+// rounds start at the root: a lone wave would spend longer staging 64 KiB than walking)
 void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, long long N, int L,
                        const float *states, const int32_t *actions, const float *rewards,
                        const float *observations, const uint8_t *dones, int D, int B, float beta,
                        unsigned long long seed, unsigned long long ctr, int from_state,
-                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw) {
-    DQN_LAUNCH(k_per_sample, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, states, actions,
-                       rewards, observations, dones, D, B, beta, seed, ctr, from_state, s, a, r, s2, d, idx, w_raw);
+                       float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw,
+                       unsigned int *wmax_bits, int num_cus) {
+    PerSampleArgs p{st, tree, N, L, states, actions, rewards, observations, dones, D, B, beta, seed, ctr, from_state,
+                    s, a, r, s2, d, idx, w_raw, wmax_bits, 0, 1};
+    const int nchunks = (B + 63) / 64;
+    if (num_cus < 1) num_cus = 256;
+    if (nchunks >= 4 * num_cus) {
+        p.TL = L < PS_TOPL ? L : PS_TOPL;
+        int wgs = (nchunks + 15) / 16; if (wgs > num_cus) wgs = num_cus;
+        p.chunks_per_wg = (nchunks + wgs - 1) / wgs;
+        wgs = (nchunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
+        const size_t lds = sizeof(float) * ((size_t)(2 << p.TL) + 16 * PS_BAND);
+        DQN_LAUNCH((k_per_sample2<16>), dim3(wgs), dim3(1024), lds, st_, p);
+    } else {
+        p.TL = 0; p.chunks_per_wg = 1;
+        DQN_LAUNCH((k_per_sample2<1>), dim3(nchunks), dim3(64), sizeof(float) * PS_BAND, st_, p);
+    }
 }
 
-void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st) {
-    hipLaunchKernelGGL(k_isw_normalize, dim3((B + 255) / 256), dim3(256), 0, st_, w_raw, B, isw, st);
+void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st, const unsigned int *wmax_bits) {
+    hipLaunchKernelGGL(k_isw_normalize, dim3((B + 255) / 256), dim3(256), 0, st_, w_raw, B, isw, st, wmax_bits);
 }
 
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,

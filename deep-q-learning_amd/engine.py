@@ -41,6 +41,8 @@ class EngineConfig:
     seed: int = 0
     world_size: int = 1
     n_step: int = 1                   # n-step returns of the device-resident vector actor (not in the reference)
+    flags: int = 0                    # dqn_flags (diagnostics): _lib.FLAG_NO_HANDOVER | FLAG_NO_ACTOR16 | FLAG_BF16_F32_ACTOR
+    obs_time_feature: bool = False    # device-resident envs append step/max_steps (LunarLander/env.py:19-24)
 
     @property
     def dims(self):
@@ -84,6 +86,7 @@ class Engine:
         c.gamma, c.per_alpha, c.per_eps, c.per_beta = cfg.gamma, cfg.per_alpha, cfg.per_eps, cfg.per_beta
         c.precision = {"f32": L.PREC_F32, "bf16": L.PREC_BF16}[cfg.precision]
         c.seed, c.world_size, c.n_step = cfg.seed, cfg.world_size, cfg.n_step
+        c.flags, c.obs_time_feature = int(cfg.flags), int(cfg.obs_time_feature)
         h = C.c_void_p()
         L.check(self.lib.dqn_create(C.byref(c), C.byref(h)))
         self.h = h
@@ -214,6 +217,12 @@ class Engine:
         L.check(self.lib.dqn_per_sample(self.h, B, float(beta), seed, ctr, _ptr(s), _ptr(a), _ptr(r), _ptr(s2),
                                         _ptr(d), _ptr(idx), _ptr(isw), self._s()))
         return (s, a, r, s2, d), idx, isw
+
+    def per_sample_into(self, B, beta, seed, ctr, bufs):
+        """per_sample into caller-held buffers (s, a, r, s2, d, idx, isw): no allocation between launches"""
+        s, a, r, s2, d, idx, isw = bufs
+        L.check(self.lib.dqn_per_sample(self.h, B, float(beta), seed, ctr, _ptr(s), _ptr(a), _ptr(r), _ptr(s2),
+                                        _ptr(d), _ptr(idx), _ptr(isw), self._s()))
 
     def per_update(self, idx, td_abs):
         idx, td_abs = self.dev(idx, torch.int32), self.dev(td_abs, torch.float32)
@@ -355,6 +364,18 @@ class Engine:
             dist.broadcast(t, src=0)
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
         L.check(self.lib.dqn_comm_init(self.h, uid, rank, world))
+
+    def comm_ranks(self) -> int:
+        """ranks of the handle's own RCCL communicator (ncclCommCount); 0 without one"""
+        n = C.c_int32()
+        L.check(self.lib.dqn_comm_count_host(self.h, C.byref(n)))
+        return n.value
+
+    def device_errors(self) -> int:
+        """in-kernel hand-over waits that gave up since the handle was created (synchronises); must be 0"""
+        n = C.c_int64()
+        L.check(self.lib.dqn_device_errors_host(self.h, C.byref(n)))
+        return n.value
 
     def allreduce_grads_native(self, stream=None):
         L.check(self.lib.dqn_allreduce_grads(self.h, self._s(stream)))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DQN_ABI_VERSION 1
+#define DQN_ABI_VERSION 2
 
 typedef enum {
     DQN_OK = 0,
@@ -47,6 +47,16 @@ typedef enum {                                                              /* d
 } dqn_buffer_id;
 
 typedef enum { DQN_ENV_SYNTHETIC = 0, DQN_ENV_CARTPOLE = 1 } dqn_env_kind;   /* device-resident vector envs */
+
+/* dqn_config.flags (diagnostics; 0 = the fast paths). */
+typedef enum {
+    DQN_FLAG_NO_HANDOVER = 1,      /* no workgroup of a launch ever waits for another: the actor launch carries no sampler
+                                    * workgroups (the update draws its own PER batch) and the row backward is its own launch.
+                                    * The library takes this path by itself where the device (CU count) cannot hold the
+                                    * co-resident grids; the flag forces it (tests). Same results, bit for bit. */
+    DQN_FLAG_NO_ACTOR16 = 2,       /* never the 16-env small-net actor kernel */
+    DQN_FLAG_BF16_F32_ACTOR = 4    /* bf16 mode with the exact-f32 actor chain */
+} dqn_flags;
 
 typedef struct dqn_handle dqn_handle;
 
@@ -74,6 +84,9 @@ typedef struct {
                                * vector step adds the row (s_u, a_u, R, s_{t+1}, done_n) of the window u = t-n_step+1 .. t,
                                * R = r_u + gamma*(r_{u+1} + gamma*(...)) cut after the first done; updates bootstrap
                                * with gamma^n_step. Rows from dqn_replay_add are stored as given. */
+    int32_t flags;            /* dqn_flags, or-ed */
+    int32_t obs_time_feature; /* 1: the device-resident vector envs append step/max_steps to their observation, as ObsWrapper does
+                               * (LunarLander/env.py:19-24): obs_dim then counts the augmented width (env state = obs_dim - 1) */
 } dqn_config;
 
 const char *dqn_last_error(void);
@@ -206,6 +219,12 @@ int dqn_profile_end(dqn_handle *h, void *stream, char *names_host, int32_t name_
 int dqn_comm_unique_id(void *unique_id_128);
 int dqn_comm_init(dqn_handle *h, const void *unique_id_128, int32_t rank, int32_t world);
 int dqn_allreduce_grads(dqn_handle *h, void *stream);
+int dqn_comm_count_host(dqn_handle *h, int32_t *ranks);   /* ncclCommCount of the handle's communicator (0: none) */
+
+/* In-kernel hand-over waits are bounded (0.2 s): a launch whose partner workgroups never ran ends, poisons the loss with
+ * NaN and counts here instead of hanging the GPU. Returns the count since dqn_create (synchronises); non-zero means the
+ * results since then are not to be trusted. */
+int dqn_device_errors_host(dqn_handle *h, int64_t *count);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,13 @@ void  orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilo
  * bootstraps with gamma^n_step (f32 product gamma*gamma*...). Resets the history. */
 void  orc_learner_set_nstep(orc_learner *l, int32_t n_step, int32_t n_envs);
 
+/* all-core (OpenMP) forms of the two drivers above (dqn_oracle_omp.c; one-step returns): bit-identical results, rows and
+ * weight-gradient elements spread over threads. bench.py's cpu_baseline times them beside the scalar ones. */
+int32_t orc_omp_threads(void);
+void  orc_omp_set_threads(int32_t n);
+float orc_learner_update_omp(orc_learner *l, int32_t B);
+void  orc_learner_actor_step_omp(orc_learner *l, float *obs, int32_t n, float epsilon, float p_done, uint64_t *env_ctr);
+
 #ifdef __cplusplus
 }
 #endif

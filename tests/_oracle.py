@@ -67,6 +67,8 @@ def lib():
         _lib.orc_param_count.argtypes = [Dims]
         _lib.orc_loss.restype = C.c_float
         _lib.orc_learner_update.restype = C.c_float
+        _lib.orc_learner_update_omp.restype = C.c_float
+        _lib.orc_omp_threads.restype = C.c_int32
     return _lib
 
 
@@ -209,6 +211,16 @@ class CLearner:
 
     def update(self, B):
         return lib().orc_learner_update(C.byref(self.l), C.c_int32(B))
+
+    def update_omp(self, B):
+        """all-core form (oracle/dqn_oracle_omp.c): same bits as update()"""
+        return lib().orc_learner_update_omp(C.byref(self.l), C.c_int32(B))
+
+    def actor_step_omp(self, obs, epsilon, p_done, env_ctr):
+        c = C.c_uint64(env_ctr)
+        lib().orc_learner_actor_step_omp(C.byref(self.l), _p(obs), C.c_int32(obs.shape[0]), C.c_float(epsilon),
+                                         C.c_float(p_done), C.byref(c))
+        return c.value
 
     def _arr(self, p, n, t=C.c_float):
         return np.ctypeslib.as_array(p, shape=(n,)).copy()

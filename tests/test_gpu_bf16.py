@@ -135,20 +135,20 @@ def test_bf16_actor_loop_runs(dq):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_fused_row_backward_equals_separate_launch(dq, precision, monkeypatch):
-    """the row backward riding in the forward launch (pass-0 workgroups continue after the partners' Q-row hand-over)
-    is the same arithmetic as k_bwd_rows / k_bwd_rows16 in its own launch: identical parameters, tree and loss after a
-    captured loop, bit for bit, in both precision modes"""
+def test_fused_row_backward_equals_separate_launch(dq, precision):
+    """the paths whose workgroups wait for each other inside a launch (PER batch drawn by the actor launch's sampler
+    workgroups; row backward riding in the forward launch after the partners' Q-row hand-over) against the path without
+    any in-launch wait (dqn_config.flags = DQN_FLAG_NO_HANDOVER: the library's fallback for devices that cannot hold the
+    co-resident grids -- the update draws its own batch, k_bwd_rows / k_bwd_rows16 is its own launch): identical
+    parameters, tree, sampled indices and loss after a captured loop, bit for bit, in both precision modes; no bounded
+    wait gave up"""
     import torch
     dims = CFGS["cfg2"]
     out = {}
     for fused in (True, False):
-        if fused:
-            monkeypatch.delenv("DQN_NO_FUSE_ROWS", raising=False)
-        else:
-            monkeypatch.setenv("DQN_NO_FUSE_ROWS", "1")                  # read when the handle is created
         e = dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=1 << 12,
-                                      use_per=True, max_batch=1024, seed=3, precision=precision))
+                                      use_per=True, max_batch=1024, seed=3, precision=precision,
+                                      flags=0 if fused else dq._lib.FLAG_NO_HANDOVER))
         e.set_params(rand_params(dims, 10)); e.sync_target()
         rng = np.random.default_rng(11)
         e.replay_add(rng.standard_normal((2048, 8)), rng.integers(0, 4, 2048), rng.standard_normal(2048),
@@ -158,10 +158,13 @@ def test_fused_row_backward_equals_separate_launch(dq, precision, monkeypatch):
             for _ in range(3):
                 e.train_iters(4, 4, 1024)
             e.stream.synchronize()
-        out[fused] = (e.get_params(host=True), host(e.buffer(dq._lib.BUF_TREE)).copy(), float(e.last_loss().item()))
+        out[fused] = (e.get_params(host=True), host(e.buffer(dq._lib.BUF_TREE)).copy(), float(e.last_loss().item()),
+                      host(e.buffer(dq._lib.BUF_BATCH_IDX, torch.int32))[:1024].copy())
+        assert e.device_errors() == 0
         e.close()
     assert np.array_equal(out[True][0], out[False][0])
     assert np.array_equal(out[True][1], out[False][1])
+    assert np.array_equal(out[True][3], out[False][3])
     assert out[True][2] == out[False][2] and np.isfinite(out[True][2])
 
 

@@ -258,6 +258,54 @@ def test_per_bitexact(dq, L_, n_add, B):
     e.close()
 
 
+@pytest.mark.parametrize("L_,fill,B,D", [
+    (16, 1.0, 70001, 8),        # 16-wave workgroups, shared top image (13 levels) + one band round, ragged last chunk
+    (20, 1.0, 1 << 18, 8),      # BASELINE ring size, sweep point: N / B = 4
+    (20, 1.0, 1 << 20, 8),      # BASELINE ring size, B = N (the bandwidth point of the sweep)
+    (12, 1.0, 65536 + 17, 9),   # whole tree inside the top image (L < 13), D not a multiple of 4, heavy duplicates
+    (18, 0.7, 300000, 4),       # one 16-byte piece per row, ring 70 % full
+    (20, 1.0, 4096, 8),         # few chunks: one-wave workgroups, bands from the root, per-lane tail (B << N)
+    (15, 0.5, 66000, 8),        # priorities planted beyond `size`: the clamp to size - 1 (and its leaf re-read) is taken
+])
+def test_per_sample_regimes_bitexact(dq, L_, fill, B, D):
+    """k_per_sample2 (LDS-staged tree top, per-wave bands, lane-cooperative 16-byte gathers) in every regime of its
+    launcher against the CPU restatement's plain descent: indices, IS weights (bits) and the five gathered arrays
+    identical; indices sorted (the property the band walk relies on)"""
+    import torch
+    dims = (D, 16, 16, 2)
+    N = 1 << L_
+    n_add = int(N * fill)
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    rng = np.random.default_rng(70 + L_ + D)
+    for k in range(0, n_add, 1 << 16):
+        n = min(1 << 16, n_add - k)
+        s = rng.standard_normal((n, D)).astype(np.float32); s2 = rng.standard_normal((n, D)).astype(np.float32)
+        a = rng.integers(0, 2, n).astype(np.int32); r = rng.standard_normal(n).astype(np.float32); d = rng.random(n) < 0.1
+        slots = cr.add(s, a, r, s2, d); ct.add(slots); e.replay_add(s, a, r, s2, d)
+        pr = (rng.random(n).astype(np.float32) + np.float32(1e-3)) ** np.float32(0.6)
+        ct.set(slots, pr); e.per_set(slots, pr)
+    if fill == 0.5:                                           # mass beyond the filled part: samples landing there are clamped
+        extra = np.arange(n_add, n_add + 3000, dtype=np.int32)
+        pr = np.full(extra.size, 5.0, np.float32)
+        ct.set(extra, pr); e.per_set(extra, pr)
+    assert np.array_equal(host(e.buffer(dq._lib.BUF_TREE)).view(np.uint32), ct.tree.view(np.uint32))
+    for it, beta in enumerate((0.4, 1.0)):
+        batch, idx, isw = e.per_sample(B, beta, seed=21, ctr=it)
+        torch.cuda.synchronize()
+        ci, cw = ct.sample(cr.size, B, beta, 21, it)
+        gi = host(idx)
+        assert np.array_equal(gi, ci), (np.flatnonzero(gi != ci)[:8], gi[gi != ci][:8], ci[gi != ci][:8])
+        assert np.all(np.diff(ci) >= 0)
+        if fill == 0.5:
+            assert (ci == cr.size - 1).sum() > 10              # the clamp really happened
+        assert np.array_equal(host(isw).view(np.uint32), cw.view(np.uint32))
+        for x, y in zip(batch, cr.gather(ci)):
+            assert np.array_equal(host(x), y)
+    assert e.device_errors() == 0
+    e.close()
+
+
 # ---------------------------------------------------------------------------- policy
 def test_act_parity(dq):
     """compute_action (:67-73) + Agent._policy (q_agent.py:137-141), vectorised"""
@@ -567,8 +615,12 @@ def test_data_parallel_halves_match_oracle(dq, world):
 
 
 def test_native_rccl_world1_and_capture(dq):
-    """the C ABI's own RCCL path (dqn_comm_unique_id / dqn_comm_init / dqn_allreduce_grads, librccl via dlopen) with a
-    one-rank communicator: the all-reduce must leave the gradient unchanged, eagerly and inside a captured graph"""
+    """the C ABI's own RCCL plumbing (dqn_comm_unique_id / dqn_comm_init / dqn_allreduce_grads, librccl via dlopen) with a
+    one-rank communicator. What is true at world 1, and all this test claims: the communicator reports 1 rank, the in-place
+    all-reduce leaves the gradient unchanged, and a capture of it is EMPTY (a one-rank all-reduce enqueues nothing) -- so the
+    captured collective itself stays unverified until a run with N > 1 ranks (bench.py --gpus N checks it against
+    torch.distributed's all-reduce before using it)."""
+    import warnings
     import ctypes as C
     import torch
     dims = CFGS["cfg1"]
@@ -577,6 +629,7 @@ def test_native_rccl_world1_and_capture(dq):
     uid = (C.c_char * 128)()
     L.check(e.lib.dqn_comm_unique_id(uid))
     L.check(e.lib.dqn_comm_init(e.h, uid, 0, 1))
+    assert e.comm_ranks() == 1
     g = np.random.default_rng(0).standard_normal(e.param_count).astype(np.float32)
     e.set_params(g, L.BUF_GRAD)
     with torch.cuda.stream(e.stream):
@@ -584,8 +637,11 @@ def test_native_rccl_world1_and_capture(dq):
         e.stream.synchronize()
         assert np.array_equal(e.get_params(L.BUF_GRAD, host=True), g)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=e.stream):
-            L.check(e.lib.dqn_allreduce_grads(e.h, e._s()))
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.graph(graph, stream=e.stream):
+                L.check(e.lib.dqn_allreduce_grads(e.h, e._s()))
+        assert any("Graph is empty" in str(w.message) for w in caught), "a one-rank all-reduce was expected to capture nothing"
         graph.replay(); graph.replay()
         e.stream.synchronize()
     assert np.array_equal(e.get_params(L.BUF_GRAD, host=True), g)

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == bound, (set(declared) ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dqn_abi_version() == 1
+    assert lib.dqn_abi_version() == dq._lib.ABI_VERSION == 2
     c = dq._lib.DqnConfig()
     lib.dqn_default_config(C.byref(c))                       # Test/lunar_lander.py:23-48 defaults
     assert (c.obs_dim, c.hidden1, c.hidden2, c.num_actions, c.capacity, c.max_batch) == (9, 32, 64, 4, 100000, 64)
@@ -43,6 +43,31 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", dq._lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (dqn_[a-z_0-9]+)", out))
     assert set(declared) <= exported
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment (how the driver starts it) must itself start 2 rank
+    processes as children, rendezvous on 127.0.0.1, and relay rank 0's single JSON line with exit status 0. CPU rehearsal
+    of that path (DQN_BENCH_SPAWN_SELFTEST=1: gloo ranks, no GPU work)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DQN_BENCH_SPAWN_SELFTEST"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["allreduce_sum"] == 3.0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DQN_BENCH_SPAWN_SELFTEST")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not r.stdout.strip()
 
 
 def test_no_silent_fallback_without_gpu():

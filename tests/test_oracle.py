@@ -233,3 +233,34 @@ def test_learner_update_runs_and_learns():
     lrn = oc.CLearner(dims, oc.Opt(2e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, 64, rb, per, onp.init_params(dims, 14), 15)
     losses = [lrn.update(64) for _ in range(300)]
     assert np.isfinite(losses).all() and np.mean(losses[-20:]) < np.mean(losses[:20])
+
+
+@pytest.mark.parametrize("name,B,per_on", [("cfg1", 64, True), ("cfg2", 200, True), ("cfg3", 96, False)])
+def test_omp_driver_is_bit_identical_to_scalar_driver(name, B, per_on):
+    """oracle/dqn_oracle_omp.c (bench.py's all-core cpu_baseline leg) == the scalar whole-update driver and actor
+    step, bit for bit: losses, parameters, moments, sampled indices, ring and tree after several iterations"""
+    dims = CFGS[name]
+    L_ = 10; N = 1 << L_
+    s, a, r, s2, d = make_batch(dims, N, 21, terminal_frac=0.1)
+    runs = []
+    for omp in (False, True):
+        rb = oc.CReplay(N, dims[0]); per = oc.CPer(L_) if per_on else None
+        slots = rb.add(s, a, r, s2, d)
+        if per is not None:
+            per.add(slots)
+        lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, rb, per, onp.init_params(dims, 3), 7)
+        obs = np.random.default_rng(5).standard_normal((37, dims[0])).astype(np.float32)
+        env_ctr, losses = 0, []
+        for _ in range(5):
+            for _ in range(2):
+                env_ctr = (lrn.actor_step_omp if omp else lrn.actor_step)(obs, 0.3, 0.05, env_ctr)
+            losses.append((lrn.update_omp if omp else lrn.update)(B))
+        runs.append((np.array(losses, np.float32), lrn.params, lrn.mu, lrn.nu, obs.copy(),
+                     np.ctypeslib.as_array(lrn.l.idx, shape=(B,)).copy(), [x.copy() for x in rb.arrays()],
+                     per.tree.copy() if per is not None else np.zeros(1)))
+    assert oc.lib().orc_omp_threads() >= 1
+    for x, y in zip(runs[0][:6], runs[1][:6]):
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    for x, y in zip(runs[0][6], runs[1][6]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(runs[0][7].view(np.uint32), runs[1][7].view(np.uint32))
