@@ -125,6 +125,17 @@ struct PerSampleArgs {
     int chunks_per_wg;
 };
 
+// one chunk's descent, cut where it waits for memory: start() walks the LDS image and REQUESTS the first band (eight 8-byte
+// pieces per lane, in registers); finish() stores them to the wave's LDS slice, walks on (further bands / per-lane tail)
+// and ends with the leaf and its priority. Between the two the wave gathers the PREVIOUS chunk's rows: a wave always has
+// one chunk's band and one chunk's rows in flight.
+struct PsChunk {
+    int k0, kk; bool in_range;
+    float u; unsigned node; int lvl;
+    unsigned nf; int w, t;                   // first band: run [nf, nf + w), t levels (0: none requested)
+    float2 pc[PS_BAND / 128];
+};
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 k_per_sample2(const PerSampleArgs p) {
@@ -136,6 +147,8 @@ k_per_sample2(const PerSampleArgs p) {
     float *band = ps_lds + (TL > 0 ? (2 << TL) : 0) + wave * PS_BAND;
     int *lidx = reinterpret_cast<int *>(band);                       // the wave's 64 leaves (after the descent)
     const float *tree = p.tree;
+    const float2 *tree2 = reinterpret_cast<const float2 *>(tree);
+    float2 *band2 = reinterpret_cast<float2 *>(band);
     STAMP(3, 0);
     if (TL > 0) {                                                    // stage the top image
         const float4 *src = reinterpret_cast<const float4 *>(tree);
@@ -152,109 +165,148 @@ k_per_sample2(const PerSampleArgs p) {
     const int nchunks = (B + 63) >> 6;
     const int c_begin = blockIdx.x * p.chunks_per_wg;
     int c_end = c_begin + p.chunks_per_wg; if (c_end > nchunks) c_end = nchunks;
-    float wmx = 0.0f;
-    for (int c = c_begin + wave; c < c_end; c += WAVES) {
-        const int k0 = c << 6, k = k0 + lane;
-        const bool in_range = k < B;
-        const int kk = in_range ? k : B - 1;                         // surplus lanes redo the last sample (no stores below)
-        const u32x4 o = philox_draw(p.seed, ctr, (uint32_t)kk, DQN_STREAM_PER);
-        float u = ((float)kk + u01(o.x)) * seg;
+
+    // levels this round for a run of w nodes: the most with w * (2^(t+1) - 2) <= PS_BAND (0: run too wide for a band)
+    auto band_levels = [&](int w, int left) -> int {
+        if (w > PS_WIDE) return 0;
+        int t = 0;
+        while (t < left && (long long)w * ((4ll << t) - 2) <= PS_BAND) ++t;
+        return t;
+    };
+    // request the band of t levels below the run [nf, nf + w): level lvl+j = nodes [nf << j, (nf + w) << j), stored from
+    // float offset w * (2^j - 2). As 8-byte pieces the t levels are one flat run of w * (2^t - 1) <= PS_BAND / 2 pieces:
+    // piece q lies in level j = 1 + floor(log2(q / w + 1)) and is tree2[(nf << (j-1)) + q - w * (2^(j-1) - 1)]. Eight pieces
+    // per lane, a clamped index instead of a branch around the load.
+    auto band_request = [&](unsigned nf, int w, int t, float2 (&pc)[PS_BAND / 128]) {
+        const int total2 = w * ((1 << t) - 1);
+        const float rw = __frcp_rn((float)w);                        // (q + 0.5) / w is never within 1/(2w) of an integer
+#pragma unroll
+        for (int i = 0; i < PS_BAND / 128; ++i) {
+            const int q0 = lane + 64 * i, q = q0 < total2 ? q0 : total2 - 1;
+            const int x = (int)(((float)q + 0.5f) * rw);
+            const int jm1 = 31 - __clz(x + 1);                        // j - 1
+            pc[i] = tree2[((unsigned long long)nf << jm1) + (unsigned)(q - w * ((1 << jm1) - 1))];
+        }
+    };
+    auto band_store = [&](int w, int t, const float2 (&pc)[PS_BAND / 128]) {
+        const int total2 = w * ((1 << t) - 1);
+#pragma unroll
+        for (int i = 0; i < PS_BAND / 128; ++i) {
+            const int q0 = lane + 64 * i;
+            if (q0 < total2) band2[q0] = pc[i];
+        }
+    };
+    // walk t levels in the stored band (one wave: LDS program order makes the stores visible to the reads)
+    auto band_walk = [&](unsigned nf, int w, int t, bool to_leaf, float &u, unsigned &node, float &pleaf) {
+        for (int j = 1; j <= t; ++j) {
+            const int at = w * ((1 << j) - 2) + (int)(2u * node - (nf << j));   // slot of the left child
+            const float l = band[at];
+            if (u < l) { node = 2 * node; if (to_leaf && j == t) pleaf = l; }
+            else { u = u - l; node = 2 * node + 1; if (to_leaf && j == t) pleaf = band[at + 1]; }
+        }
+    };
+    auto start = [&](int c, PsChunk &d) {
+        d.k0 = c << 6;
+        const int k = d.k0 + lane;
+        d.in_range = k < B;
+        d.kk = d.in_range ? k : B - 1;                               // surplus lanes redo the last sample (no stores)
+        const u32x4 o = philox_draw(p.seed, ctr, (uint32_t)d.kk, DQN_STREAM_PER);
+        float u = ((float)d.kk + u01(o.x)) * seg;
         unsigned node = 1;                                           // node ids < 2^31 (capacity <= 2^30)
         for (int lvl = 0; lvl < TL; ++lvl) {
             const float l = top[2 * node];
             if (u < l) { node = 2 * node; }
             else { u = u - l; node = 2 * node + 1; }
         }
-        int lvl = TL;
-        float pleaf = 0.0f; bool have_p = false;                     // tree[node] of the final node, when it came from LDS
+        d.u = u; d.node = node; d.lvl = TL; d.t = 0; d.w = 1; d.nf = node;
+        if (TL < L) {
+            d.nf = __builtin_amdgcn_readfirstlane(node);
+            d.w = (int)(__builtin_amdgcn_readlane(node, 63) - d.nf) + 1;
+            d.t = band_levels(d.w, L - TL);
+            if (d.t > 0) band_request(d.nf, d.w, d.t, d.pc);
+        }
+    };
+    // -> leaf (clamped) and its priority
+    auto finish = [&](PsChunk &d, long long &leaf, float &pleaf) {
+        float u = d.u; unsigned node = d.node; int lvl = d.lvl;
+        bool have_p = false; pleaf = 0.0f;
         if (TL > 0 && lvl == L) { pleaf = top[node]; have_p = true; }
-        while (lvl < L) {
-            const unsigned nf = __builtin_amdgcn_readfirstlane(node), nl = __builtin_amdgcn_readlane(node, 63);
-            const int w = (int)(nl - nf) + 1;
-            if (w > PS_WIDE) break;
-            int t = 0;                                               // levels this round: w * (2^(t+1) - 2) <= PS_BAND
-            while (t < L - lvl && (long long)w * ((4ll << t) - 2) <= PS_BAND) ++t;
-            if (t == 0) break;
-            // level lvl+j of the band: nodes [nf << j, (nl + 1) << j), stored from float offset w * (2^j - 2). As 8-byte
-            // pieces the t levels are one flat run of w * (2^t - 1) <= PS_BAND / 2 pieces: piece q lies in level
-            // j = 1 + floor(log2(q / w + 1)) and is tree2[(nf << (j-1)) + q - w * (2^(j-1) - 1)]. Eight pieces per lane,
-            // every load issued before the first LDS store (clamped index instead of a branch around the load).
-            {
-                const int total2 = w * ((1 << t) - 1);
-                const float rw = __frcp_rn((float)w);                // (q + 0.5) / w is never within 1/(2w) of an integer
-                const float2 *tree2 = reinterpret_cast<const float2 *>(tree);
-                float2 *band2 = reinterpret_cast<float2 *>(band);
+        if (d.t > 0) {
+            band_store(d.w, d.t, d.pc);
+            band_walk(d.nf, d.w, d.t, lvl + d.t == L, u, node, pleaf);
+            lvl += d.t; have_p = lvl == L;
+            while (lvl < L) {                                        // run wider than one band holds: further rounds
+                const unsigned nf = __builtin_amdgcn_readfirstlane(node);
+                const int w = (int)(__builtin_amdgcn_readlane(node, 63) - nf) + 1;
+                const int t = band_levels(w, L - lvl);
+                if (t == 0) break;
                 float2 pc[PS_BAND / 128];
-#pragma unroll
-                for (int i = 0; i < PS_BAND / 128; ++i) {
-                    const int q0 = lane + 64 * i, q = q0 < total2 ? q0 : total2 - 1;
-                    const int x = (int)(((float)q + 0.5f) * rw);
-                    const int jm1 = 31 - __clz(x + 1);                // j - 1
-                    pc[i] = tree2[((unsigned long long)nf << jm1) + (unsigned)(q - w * ((1 << jm1) - 1))];
-                }
-#pragma unroll
-                for (int i = 0; i < PS_BAND / 128; ++i) {
-                    const int q0 = lane + 64 * i;
-                    if (q0 < total2) band2[q0] = pc[i];
-                }
+                band_request(nf, w, t, pc);
+                band_store(w, t, pc);
+                band_walk(nf, w, t, lvl + t == L, u, node, pleaf);
+                lvl += t; have_p = lvl == L;
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: LDS program order suffices
-            const bool to_leaf = lvl + t == L;
-            for (int j = 1; j <= t; ++j) {
-                const int at = w * ((1 << j) - 2) + (int)(2u * node - (nf << j));   // slot of the left child
-                const float l = band[at];
-                if (u < l) { node = 2 * node; if (to_leaf && j == t) pleaf = l; }
-                else { u = u - l; node = 2 * node + 1; if (to_leaf && j == t) pleaf = band[at + 1]; }
-            }
-            lvl += t;
-            have_p = to_leaf;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the band slice is rewritten next round / by lidx
         }
         for (; lvl < L; ++lvl) {                                     // sparse regime: per-lane dependent loads
             const float l = tree[2ull * node];
             if (u < l) { node = 2 * node; }
             else { u = u - l; node = 2 * node + 1; }
         }
-        long long leaf = (long long)node - p.N;
+        leaf = (long long)node - p.N;
         if (leaf >= size) { leaf = size - 1; have_p = false; }
         if (!have_p) pleaf = tree[p.N + leaf];
+    };
+
+    float wmx = 0.0f;
+    PsChunk d;
+    int c = c_begin + wave;
+    if (c < c_end) start(c, d);
+    while (c < c_end) {
+        long long leaf; float pleaf;
+        finish(d, leaf, pleaf);
+        const int k0 = d.k0, k = k0 + lane; const bool in_range = d.in_range;
         const float w_is = pow_det(__fdiv_rn((float)size * pleaf, total), -beta);
         wmx = fmaxf(wmx, w_is);
         lidx[lane] = (int)leaf;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- the five gathers (replay_buffer.py:78-84): every load first, then the stores
+        // ---- the five gathers (replay_buffer.py:78-84): every load first; the next chunk's image walk and band request;
+        // then the stores
         const int nrow = (B - k0) < 64 ? (B - k0) : 64;
         const int32_t av = p.actions[leaf]; const float rv = p.rewards[leaf]; const uint8_t dv = p.dones[leaf];
+        const int cn = c + WAVES;
         if (D == 8) {
             // a row = two 16-byte pieces; lane q handles pieces q and q + 64 of the chunk's 128 (all 64 leaves are valid rows)
             const float4 *S4 = reinterpret_cast<const float4 *>(p.states), *O4 = reinterpret_cast<const float4 *>(p.observations);
             float4 *s4 = reinterpret_cast<float4 *>(p.s) + (long long)k0 * 2, *o4 = reinterpret_cast<float4 *>(p.s2) + (long long)k0 * 2;
             const long long src0 = (long long)lidx[lane >> 1] * 2 + (lane & 1), src1 = (long long)lidx[32 + (lane >> 1)] * 2 + (lane & 1);
             const float4 a0 = S4[src0], b0 = O4[src0], a1 = S4[src1], b1 = O4[src1];
+            if (cn < c_end) start(cn, d);
             if (lane < 2 * nrow) { s4[lane] = a0; o4[lane] = b0; }
             if (lane + 64 < 2 * nrow) { s4[lane + 64] = a1; o4[lane + 64] = b1; }
-        } else if ((D & 3) == 0) {
-            const int C = D >> 2, tot = nrow * C;                    // 16-byte pieces of this chunk's rows
-            const float4 *S4 = reinterpret_cast<const float4 *>(p.states), *O4 = reinterpret_cast<const float4 *>(p.observations);
-            float4 *s4 = reinterpret_cast<float4 *>(p.s) + (long long)k0 * C, *o4 = reinterpret_cast<float4 *>(p.s2) + (long long)k0 * C;
-            for (int q = lane; q < tot; q += 64) {
-                const int smp = q / C, part = q - smp * C;
-                const long long src = (long long)lidx[smp] * C + part;
-                const float4 a4 = S4[src], b4 = O4[src];
-                s4[q] = a4; o4[q] = b4;
-            }
         } else {
-            const int tot = nrow * D;
-            float *s1 = p.s + (long long)k0 * D, *o1 = p.s2 + (long long)k0 * D;
-            for (int q = lane; q < tot; q += 64) {
-                const int smp = q / D, e = q - smp * D;
-                const long long src = (long long)lidx[smp] * D + e;
-                const float x0 = p.states[src], x1 = p.observations[src];
-                s1[q] = x0; o1[q] = x1;
+            if ((D & 3) == 0) {
+                const int C = D >> 2, tot = nrow * C;                // 16-byte pieces of this chunk's rows
+                const float4 *S4 = reinterpret_cast<const float4 *>(p.states), *O4 = reinterpret_cast<const float4 *>(p.observations);
+                float4 *s4 = reinterpret_cast<float4 *>(p.s) + (long long)k0 * C, *o4 = reinterpret_cast<float4 *>(p.s2) + (long long)k0 * C;
+                for (int q = lane; q < tot; q += 64) {
+                    const int smp = q / C, part = q - smp * C;
+                    const long long src = (long long)lidx[smp] * C + part;
+                    const float4 a4 = S4[src], b4 = O4[src];
+                    s4[q] = a4; o4[q] = b4;
+                }
+            } else {
+                const int tot = nrow * D;
+                float *s1 = p.s + (long long)k0 * D, *o1 = p.s2 + (long long)k0 * D;
+                for (int q = lane; q < tot; q += 64) {
+                    const int smp = q / D, e = q - smp * D;
+                    const long long src = (long long)lidx[smp] * D + e;
+                    const float x0 = p.states[src], x1 = p.observations[src];
+                    s1[q] = x0; o1[q] = x1;
+                }
             }
+            if (cn < c_end) start(cn, d);
         }
         if (in_range) { p.idx[k] = (int32_t)leaf; p.w_raw[k] = w_is; p.a[k] = av; p.r[k] = rv; p.d[k] = dv; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // lidx is band space of the next chunk
+        c = cn;
     }
     STAMP(3, 2);
     // batch max of the raw weights: one atomic per workgroup
