@@ -83,6 +83,7 @@ struct dqn_handle {
     float *px = nullptr, *ph1 = nullptr, *ph2 = nullptr, *pdz1 = nullptr, *pdz2 = nullptr, *pdz3 = nullptr;
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
     int *tile_cnt = nullptr;                                      // per-tile hand-over counters of the fused forward + row backward
+    float *big_slab = nullptr, *big_colsum = nullptr;             // large-batch path (dqn_net_big.hip): split-K partial tiles, per-row-tile column sums
     unsigned int *wmax_tmp = nullptr;                             // batch max of the raw IS weights (API sampler -> normalise)
     int num_cus = 256;                                            // hipDeviceAttributeMultiprocessorCount of the handle's device
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
@@ -114,8 +115,14 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
         if (pack == h->pack) { launch_pack(s, h->m, params, h->pack_act); launch_pack_w2k16(s, h->m, params, h->pack_act); }   // the actor kernel reads f32 shadows of the online net
     } else launch_pack(s, h->m, params, pack);
 }
+static bool use_big(dqn_handle *h, int B) { return h->big_slab != nullptr && big_supported(h->m, B); }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
                   const BwdArgs *fuse = nullptr) {
+    if (use_big(h, B) && !smp && !fuse) {                          // large batches: 64-row tiles (dqn_net_big.hip), forward only
+        bool plain = true;
+        for (int i = 0; i < n; ++i) plain = plain && !p[i].act_out && !p[i].px && p[i].x;
+        if (plain) { launch_big_forward(s, h->m, p, n, B, h->num_cus); return; }
+    }
     if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
     else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
 }
@@ -178,7 +185,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
     h->gamma_n = cfg->gamma;
     for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
-    h->Bp = h->bf16 ? (cfg->max_batch + 31) / 32 * 32 : (cfg->max_batch + 15) / 16 * 16;
+    h->Bp = h->bf16 ? (cfg->max_batch + 31) / 32 * 32 : (cfg->max_batch + 63) / 64 * 64;   // whole row tiles of every kernel family
     if (cfg->use_per) {
         int L = 0; while ((1ll << L) < cfg->capacity) ++L;
         if (L < 1) L = 1;
@@ -210,6 +217,9 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
+    if (!h->bf16 && big_supported(h->m, cfg->max_batch)) {
+        add(&h->big_slab, big_slab_floats(cfg->max_batch, h->num_cus) * 4); add(&h->big_colsum, big_colsum_floats(cfg->max_batch) * 4);
+    }
     h->tile_stride = (int)(Bp / 16) + 2;
     add(&h->tile_cnt, (size_t)h->tile_stride * 2 * 4); add(&h->wmax_tmp, 4);
     add(&h->env_obs, Bp * D * 4, DQN_BUF_ENV_OBS); add(&h->env_next, Bp * D * 4); add(&h->env_r, Bp * 4);
@@ -478,11 +488,18 @@ extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, co
     REQUIRE(B >= 1 && B <= h->cfg.max_batch, "B=%d exceeds max_batch=%d", B, h->cfg.max_batch);
     hipStream_t st = (hipStream_t)stream;
     FwdPass p = make_pass(h, DQN_NET_ONLINE, s, h->q, nullptr, true);
-    L_fwd(h, st, &p, 1, B);
     BwdArgs g{};
     g.q = h->q; g.targets = targets; g.isw = isw; g.gamma = h->cfg.gamma;
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3; g.loss_part = h->loss_part;
+    if (use_big(h, B)) {                                           // forward + row backward of a row tile in one workgroup, split-K dW
+        launch_big_rows_bwd(st, h->m, &p, 1, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        launch_big_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
+                      h->loss_part, loss ? loss : h->loss_dev, h->st, 0, AdamArgs{}, h->num_cus);
+        HIP_TRY(hipGetLastError());
+        return DQN_OK;
+    }
+    L_fwd(h, st, &p, 1, B);
     L_bwd(h, st, g, B);
     L_dw(h, st, B, loss ? loss : h->loss_dev, 0, AdamArgs{}, PwArgs{});
     HIP_TRY(hipGetLastError());
@@ -528,6 +545,39 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
 // parallel branch of the captured graph (it only needs idx and |delta|), joined by join_update().
 static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_adam = false, bool fuse_pw = false,
                              bool defer_top = false, bool presampled = false) {
+    if (use_big(h, B) && !presampled) {
+        // large batches (dqn_net_big.hip): the batch is drawn and gathered by the stand-alone sampler, then ONE launch takes
+        // each 64-row tile through the three forwards, the TD rule and the row backward, then the split-K weight gradients
+        // with the optimizer in the reduction, then the priority write-back
+        if (h->cfg.use_per) {
+            arm(h);
+            launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations, h->dones,
+                              h->cfg.obs_dim, B, 0.0f, h->cfg.seed, 0, 1, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx, h->bw_raw,
+                              reinterpret_cast<unsigned int *>(&h->st->wmax), h->num_cus);
+            mark(h, st, "per_sample");
+        } else {
+            launch_sample_uniform(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones, h->cfg.obs_dim, B,
+                                  h->cfg.seed, 0, 1, nullptr, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx);
+        }
+        FwdPass p[3] = { make_pass(h, DQN_NET_ONLINE, h->bs2, h->nq, nullptr, false),     // :53
+                         make_pass(h, DQN_NET_TARGET, h->bs2, h->nt, nullptr, false),     // :54
+                         make_pass(h, DQN_NET_ONLINE, h->bs, h->q, nullptr, false) };     // :52 (= pred of :35)
+        BwdArgs g{};
+        g.a = h->ba; g.r = h->br; g.d_u8 = h->bd; g.w_raw = h->cfg.use_per ? h->bw_raw : nullptr;
+        g.gamma = h->n_step > 1 ? h->gamma_n : h->cfg.gamma;
+        g.pack = h->pack; g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
+        g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
+        arm(h);
+        launch_big_rows_bwd(st, h->m, p, 3, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        mark(h, st, "big_rows_fwd3_bwd");
+        arm(h);
+        launch_big_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
+                      h->loss_part, h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{}, h->num_cus);
+        mark(h, st, "big_dw");
+        if (fuse_pw && h->cfg.use_per) enqueue_per_writeback(h, B, st);
+        (void)defer_top;
+        return;
+    }
     // q_agent.py:147-153 sample_batch + :159-165 compute_q_targets' three forwards, ONE launch: every forward
     // workgroup draws its own 16 rows (stratified PER descent or uniform Philox index) and reads them from the ring
     SampleArgs sm{};
@@ -619,6 +669,7 @@ static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
     arm(h);
     // bf16 mode: the same kernel on v_mfma_f32_4x4x4_16b_bf16 (weights / activations rounded to bf16 in registers from
     // the f32 shadows in pack_act: chains a quarter as long)
+    if (presample_B > 0 && use_big(h, presample_B)) presample_B = 0;   // large batches draw their rows in the update (k_per_sample2)
     const bool pre = launch_actor_multi(st, h->m, e, T, h->params, h->bf16 ? h->pack_act : h->pack, h->env_a,
                                         (h->cfg.use_per && !h->no_handover ? presample_B : 0), &sm, h->bf16 && !h->f32_actor,
                                         h->num_cus, h->no_actor16);

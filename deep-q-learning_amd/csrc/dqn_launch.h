@@ -110,6 +110,19 @@ void launch_policy(hipStream_t s, const float *q, int n, int A, float epsilon, u
                    unsigned long long ctr, int32_t *actions, const DqnState *st_from);
 void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
 
+// ----- large-batch f32 kernels (dqn_net_big.hip): 64 rows per workgroup on v_mfma_f32_32x32x2_f32 -------------
+#define DQN_BIG_MIN 8192            // batch rows from which the 64-row kernels replace the 16-row ones
+#define DQN_BIG_MAX_SLICES 64       // batch slices of the split-K weight-gradient GEMM (slab size)
+bool big_supported(const NetDims &m, int B);
+size_t big_slab_floats(int max_batch, int num_cus);
+size_t big_colsum_floats(int max_batch);
+void launch_big_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus);
+void launch_big_rows_bwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const BwdArgs &bw,
+                         float *px, float *ph1, float *ph2, float *colsum, DqnState *st, int num_cus);
+void launch_big_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2, const float *pdz1,
+                   const float *pdz2, const float *pdz3, int B, float *slab, const float *colsum, float *grad,
+                   const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam, int num_cus);
+
 // ----- replay / PER ---------------------------------------------------------------------
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
                        float *observations, uint8_t *dones, long long N, int D, const float *s,

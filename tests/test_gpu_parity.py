@@ -38,7 +38,8 @@ def rand_params(dims, seed):
 
 
 # ------------------------------------------------------------------------- forward
-@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg1", 1), ("cfg1", 37), ("cfg2", 1024), ("cfg3", 8192), ("cfg2", 100)])
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg1", 1), ("cfg1", 37), ("cfg2", 1024), ("cfg3", 8192), ("cfg2", 100),
+                                    ("cfg2", 8200)])          # 8200 rows of the 2x256 net: the 64-row kernels (dqn_net_big.hip), ragged last tile
 def test_forward_parity(dq, name, B):
     """Model.__call__ (LunarLander/dddqn.py:24-34)"""
     dims = CFGS[name]
@@ -62,7 +63,7 @@ def test_forward_parity(dq, name, B):
 
 
 # ------------------------------------------------------------------------- targets
-@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 512)])
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 512), ("cfg2", 8200)])
 def test_q_targets_parity(dq, name, B):
     """compute_q_targets (q_learning_functions.py:42-64) incl. quirks Q3/Q4 and argmax ties"""
     dims = CFGS[name]
@@ -91,7 +92,7 @@ def test_q_targets_parity(dq, name, B):
 
 
 # ----------------------------------------------------------------- loss / gradients
-@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 8192), ("cfg1", 50)])
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 8192), ("cfg1", 50), ("cfg2", 8200), ("cfg2", 16384)])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_loss_and_grads_parity(dq, name, B, weighted):
     """compute_loss (:31-39) and jax.grad(compute_loss) (:23)"""
@@ -320,7 +321,8 @@ def test_act_parity(dq):
 
 
 # ------------------------------------------------------------------ the fused update
-@pytest.mark.parametrize("name,B,per", [("cfg1", 64, False), ("cfg1", 64, True), ("cfg2", 1024, True), ("cfg3", 2048, True)])
+@pytest.mark.parametrize("name,B,per", [("cfg1", 64, False), ("cfg1", 64, True), ("cfg2", 1024, True), ("cfg3", 2048, True),
+                                        ("cfg2", 8200, True), ("cfg2", 8192, False)])      # >= 8192 rows of the 2x256 net: dqn_net_big.hip
 def test_fused_update_tracks_oracle(dq, name, B, per):
     """Agent._step (q_agent.py:146-169) as dqn_update_fused, 4 consecutive updates (graph replays) with a
     target sync in between, against the C oracle's whole-update driver on the same replay contents.
@@ -330,7 +332,8 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
     D, A = dims[0], dims[3]
     L_ = 12
     N = 1 << L_
-    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=1e-3)
+    lr = 1e-3 if B < 8192 else 2e-4          # (8 192-row sums: two f32 summation orders differ by ~1e-5 * lr / 1e-3 after the optimizer; the reference's lr)
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=lr)
     cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
     s, a, r, s2, d = make_batch(dims, 3000, 70, terminal_frac=0.1)
     r = np.clip(r, -2, 2)
@@ -342,9 +345,13 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
         e.replay_add(s[sl], a[sl], r[sl], s2[sl], d[sl] > 0)
     P0 = rand_params(dims, 71)
     e.set_params(P0); e.set_params(P0, dq._lib.BUF_TARGET)
-    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 77, beta=0.4)
+    lrn = oc.CLearner(dims, oc.Opt(lr, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 77, beta=0.4)
     with torch.cuda.stream(e.stream):
-        for it in range(4):
+        # (two lock-step trajectories stay index-identical only while no stratified draw falls within rounding distance of
+        # a priority boundary: with 8 200 draws per update that is a matter of a few updates -- seen at the third -- so the
+        # large batches are compared over two updates)
+        n_it = 4 if B < 8192 else 2
+        for it in range(n_it):
             Lc = lrn.update(B)
             e.update(B)
             e.stream.synchronize()
@@ -356,10 +363,11 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
                 e.sync_target(); lrn.sync_target()
     Pg = e.get_params(host=True)
     assert np.max(np.abs(Pg - lrn.params)) <= 1e-5, np.max(np.abs(Pg - lrn.params))
-    assert e.opt_count() == 4
+    assert e.opt_count() == n_it
     if per:
         # priorities come from |delta| (FP, 1e-5-level differences) -> tree close, not bitwise
         assert np.allclose(host(e.buffer(dq._lib.BUF_TREE)), ct.tree, rtol=1e-4, atol=1e-6)
+    assert e.device_errors() == 0
     e.close()
 
 

@@ -36,10 +36,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-log2", type=int, default=17)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-actor", action="store_true")
     args = ap.parse_args()
+    peak = 157.3 if args.precision == "f32" else 2500.0
     maxB = 1 << args.max_log2
     eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << L, use_per=True,
-                                    max_batch=maxB, seed=3))
+                                    max_batch=maxB, seed=3, precision=args.precision))
     gen = torch.Generator(device=eng.device); gen.manual_seed(0)
     eng.set_params(torch.randn(eng.param_count) * 0.05); eng.sync_target()
     bench.prefill(eng, gen)
@@ -63,15 +66,20 @@ def main():
             t = timed(lambda: eng.lib.dqn_grads(eng.h, x.data_ptr(), tg.data_ptr(), None, B, None, eng._s()), reps, st)
             bk = F + 2 * (H1 * H2 + H2 * (1 + A))
             r["grads_us"] = t * 1e6; r["grads_TFs"] = (F + bk) * B / t / 1e12          # 1 fwd + bwd
+            # the whole Agent._step on the handle's replay: PER sample, 3 forwards, TD, row backward, dW, AdamW, write-back
+            t = timed(lambda: eng.update(B, st), max(3, reps // 2), st)
+            r["update_us"] = t * 1e6; r["update_TFs"] = (3 * F + bk) * B / t / 1e12
+            for k in ("fwd", "grads", "update"):
+                r[k + "_frac_of_mfma_peak"] = r[k + "_TFs"] / peak
             rows.append(r)
             print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
     # k_actor (4 vector env steps per launch) over the number of envs: 4-env tiles, <= 255 actor workgroups
     actor_rows = []
     eng.close()
-    for ln in range(8, 17, 2):
+    for ln in ([] if args.no_actor else range(8, 17, 2)):
         n = 1 << ln
         eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << L, use_per=True,
-                                        max_batch=max(n, 1024), seed=3))
+                                        max_batch=max(n, 1024), seed=3, precision=args.precision))
         eng.set_params(torch.randn(eng.param_count) * 0.05)
         eng.env_reset(torch.randn(n, D, device=eng.device), 0.01); eng.set_epsilon(0.15)
         with torch.cuda.stream(eng.stream):
@@ -80,8 +88,8 @@ def main():
         actor_rows.append(r)
         print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
         eng.close()
-    out = {"config": {"D": D, "H1": H1, "H2": H2, "A": A, "log2N": L, "dtype": "f32"},
-           "peaks": {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3}, "rows": rows, "actor_rows": actor_rows}
+    out = {"config": {"D": D, "H1": H1, "H2": H2, "A": A, "log2N": L, "dtype": args.precision},
+           "peaks": {"hbm_GBs": 8000.0, "mfma_TFs": peak}, "rows": rows, "actor_rows": actor_rows}
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 
