@@ -397,6 +397,20 @@ def per_sample_lines(dq, rank):
     return out
 
 
+def per_sample_child():
+    """per_sample_lines in a child process of its own (started, not exec'ed). The sampler at B = 2^20 is sensitive to where
+    the handle's arena lands: the FIRST device allocation of a process gathers at 37-39 us, a handle created after another
+    one (alive or freed, torch cache emptied or not) at 54-56 us (tools/diag/ps_repro.py) -- so it is measured the way a
+    long-lived learner process would see it, as that process's first handle; the in-process figure is kept beside it."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--per-sample-only"], capture_output=True, text=True, timeout=600)
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            return json.loads(ln)
+    print(f"[bench] per-sample child failed (exit {r.returncode}): {r.stderr[-500:]}", file=sys.stderr)
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,6 +420,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=50)
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary bf16 measurement and the PER-sample lines")
+    ap.add_argument("--per-sample-only", action="store_true", help=argparse.SUPPRESS)   # child mode: the stand-alone sampler lines only
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = exact f32 MFMA (meets the 1e-5 parity bar; default); bf16 = bf16 MFMA throughput path")
     args = ap.parse_args()
@@ -425,6 +440,10 @@ def main():
     if os.environ.get("DQN_BENCH_SPAWN_SELFTEST") == "1":
         return spawn_selftest(args, json_fd)
     torch.cuda.set_device(local_rank)
+    if args.per_sample_only:
+        import deep_q_learning_amd as dq
+        os.write(json_fd, (json.dumps(per_sample_lines(dq, rank)) + "\n").encode())
+        return
     import torch.distributed as dist
     # DQN_BENCH_FORCE_DP=1: take the multi-GPU code path with one rank (plumbing rehearsal on a 1-GPU box; a one-rank
     # all-reduce moves nothing, so this says nothing about the collective itself)
@@ -628,7 +647,7 @@ def main():
         if world == 1 and not dp and args.precision == "f32" and not args.no_secondary:
             eng.close()
             out["bf16"] = quick_rate(dq, "bf16", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH))
-            out["kernels"].update(per_sample_lines(dq, rank))
+            out["kernels"].update(per_sample_child())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
