@@ -4,6 +4,7 @@ generate_q_target_comp, generate_train_step, action_computation, Agent._step) on
 hand-written HIP kernels behind a C ABI (include/dqn_hip.h). Import as `deep_q_learning_amd`.
 """
 from . import _lib
+from .cnn import CnnEngine
 from .engine import Engine, EngineConfig
 
-__all__ = ["Engine", "EngineConfig", "_lib"]
+__all__ = ["Engine", "EngineConfig", "CnnEngine", "_lib"]

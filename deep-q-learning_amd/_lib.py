@@ -27,7 +27,7 @@ class DqnConfig(C.Structure):
                 ("b2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("gamma", C.c_float),
                 ("per_alpha", C.c_float), ("per_eps", C.c_float), ("per_beta", C.c_float),
                 ("precision", C.c_int32), ("seed", C.c_uint64), ("world_size", C.c_int32),
-                ("n_step", C.c_int32), ("flags", C.c_int32), ("obs_time_feature", C.c_int32)]
+                ("n_step", C.c_int32), ("flags", C.c_int32)]
 
 
 _P, _I32, _I64, _U64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -77,6 +77,12 @@ SIGNATURES = {
     "dqn_allreduce_grads": [_P, _P],
     "dqn_comm_count_host": [_P, C.POINTER(_I32)],
     "dqn_device_errors_host": [_P, C.POINTER(_I64)],
+    "dqn_cnn_create": [_I32, _I32, _I32, C.POINTER(_P)],
+    "dqn_cnn_destroy": [_P],
+    "dqn_cnn_param_count": [_P, C.POINTER(_I64)],
+    "dqn_cnn_set_params": [_P, C.c_int, _P, C.c_int, _P],
+    "dqn_cnn_forward": [_P, C.c_int, _P, _I32, _P, _P],
+    "dqn_cnn_q_targets": [_P, _P, _P, _P, _P, _P, _F, _I32, _P, _P],
 }
 OTHER = {"dqn_last_error": ([], C.c_char_p), "dqn_abi_version": ([], C.c_int),
          "dqn_default_config": ([C.POINTER(DqnConfig)], None)}

@@ -1,0 +1,72 @@
+"""Nature-CNN dueling Q-network, forward (BASELINE.json configs[4], PongNoFrameskip-v4 shape).
+The reference has no CNN: this is the model a `Model`-like object would wrap for Atari, ending in the reference's dueling
+head (LunarLander/dddqn.py:29-31) and feeding the reference's TD rule (General/QLearning/q_learning_functions.py:55-60).
+Every computation goes through the C ABI (include/dqn_hip.h: dqn_cnn_*); there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import _ptr
+
+
+class CnnEngine:
+    def __init__(self, num_actions: int = 6, max_batch: int = 512, precision: str = "bf16", device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("deep_q_learning_amd needs an MI355X (gfx950) GPU: torch.cuda is not available "
+                               "and there is no CPU fallback")
+        self.lib = L.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.num_actions, self.max_batch, self.precision = num_actions, max_batch, precision
+        h = C.c_void_p()
+        L.check(self.lib.dqn_cnn_create(num_actions, max_batch, {"f32": L.PREC_F32, "bf16": L.PREC_BF16}[precision], C.byref(h)))
+        self.h = h
+        n = C.c_int64()
+        L.check(self.lib.dqn_cnn_param_count(self.h, C.byref(n)))
+        self.param_count = n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dqn_cnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _frames(self, x):
+        x = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        x = x.to(self.device, torch.uint8).contiguous()
+        assert x.shape[1:] == (84, 84, 4), x.shape
+        return x
+
+    def set_params(self, flat, target=False):
+        a = np.ascontiguousarray(np.asarray(flat.cpu() if isinstance(flat, torch.Tensor) else flat, np.float32))
+        assert a.size == self.param_count, (a.size, self.param_count)
+        L.check(self.lib.dqn_cnn_set_params(self.h, L.NET_TARGET if target else L.NET_ONLINE, a.ctypes.data_as(C.c_void_p), 1, self._s()))
+
+    def forward(self, frames, target=False, out=None):
+        """frames: u8 [B, 84, 84, 4] (four stacked frames, NHWC) -> Q [B, A]"""
+        x = self._frames(frames)
+        q = out if out is not None else torch.empty((x.shape[0], self.num_actions), dtype=torch.float32, device=self.device)
+        L.check(self.lib.dqn_cnn_forward(self.h, L.NET_TARGET if target else L.NET_ONLINE, _ptr(x), x.shape[0], _ptr(q), self._s()))
+        return q
+
+    def q_targets(self, s, a, r, s2, d, gamma=0.99):
+        """compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model"""
+        s, s2 = self._frames(s), self._frames(s2)
+        B = s.shape[0]
+        t = lambda v, dt: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))).to(self.device, dt).contiguous()
+        a, r, d = t(a, torch.int32), t(r, torch.float32), t(d, torch.float32)
+        out = torch.empty((B, self.num_actions), dtype=torch.float32, device=self.device)
+        L.check(self.lib.dqn_cnn_q_targets(self.h, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), float(gamma), B, _ptr(out), self._s()))
+        return out

@@ -24,6 +24,7 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+int dqn_set_error(int code, const char *msg) { g_err = msg; return code; }    // for the other translation units (dqn_cnn.hip)
 #define HIP_TRY(expr)                                                                          \
     do { hipError_t e_ = (expr);                                                               \
          if (e_ != hipSuccess) return fail(DQN_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -42,7 +43,7 @@ extern "C" void dqn_default_config(dqn_config *c) {
     c->weight_decay = 1e-4f; c->gamma = 0.99f;
     c->per_alpha = 0.6f; c->per_eps = 1e-6f; c->per_beta = 0.4f;
     c->precision = DQN_PREC_F32; c->seed = 0; c->world_size = 1;
-    c->n_step = 1; c->flags = 0; c->obs_time_feature = 0;
+    c->n_step = 1; c->flags = 0;
 }
 
 // ------------------------------------------------------------------------------ handle

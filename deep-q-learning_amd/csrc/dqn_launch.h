@@ -6,6 +6,8 @@
 
 #include <hip/hip_ext.h>
 
+int dqn_set_error(int code, const char *msg);   // dqn_api.hip: message returned by dqn_last_error()
+
 struct EnvArgs;   // dqn_per_device.h
 struct SampleArgs;
 

@@ -42,7 +42,6 @@ class EngineConfig:
     world_size: int = 1
     n_step: int = 1                   # n-step returns of the device-resident vector actor (not in the reference)
     flags: int = 0                    # dqn_flags (diagnostics): _lib.FLAG_NO_HANDOVER | FLAG_NO_ACTOR16 | FLAG_BF16_F32_ACTOR
-    obs_time_feature: bool = False    # device-resident envs append step/max_steps (LunarLander/env.py:19-24)
 
     @property
     def dims(self):
@@ -86,7 +85,7 @@ class Engine:
         c.gamma, c.per_alpha, c.per_eps, c.per_beta = cfg.gamma, cfg.per_alpha, cfg.per_eps, cfg.per_beta
         c.precision = {"f32": L.PREC_F32, "bf16": L.PREC_BF16}[cfg.precision]
         c.seed, c.world_size, c.n_step = cfg.seed, cfg.world_size, cfg.n_step
-        c.flags, c.obs_time_feature = int(cfg.flags), int(cfg.obs_time_feature)
+        c.flags = int(cfg.flags)
         h = C.c_void_p()
         L.check(self.lib.dqn_create(C.byref(c), C.byref(h)))
         self.h = h

@@ -33,8 +33,53 @@ class GradientTransformation:
         return (adam, EmptyState(), EmptyState()) if self.kind == "adamw" else (adam, EmptyState())
 
     def update(self, grads, state, params=None):
-        raise NotImplementedError("the update is fused into train_step (generate_train_step); "
-                                  "optimizer.update is not a separate device pass in this build")
+        """optax's `updates, opt_state = optimizer.update(grads, opt_state, params)` (q_learning_functions.py:24):
+        one dqn_optimizer_step (k_adam) on a handle of the parameters' shape -- bit-exact scale_by_adam ->
+        (adamw: add_decayed_weights) -> scale(-lr). Returns (updates, new_state); `updates` remembers the parameters
+        the device pass produced, so that apply_updates(params, updates) returns exactly those bits."""
+        from . import _lib as L
+        from ._tree import dims_of, flatten, unflatten
+        from .engine import Engine, EngineConfig
+        if params is None:
+            if self.kind == "adamw":
+                raise ValueError("adamw needs `params` (weight decay), as optax.adamw does")
+            params = {mod: {leaf: torch.zeros_like(torch.as_tensor(t)) for leaf, t in leaves.items()} for mod, leaves in grads.items()}
+        dims = dims_of(params)
+        cache = _ENGINES
+        e = cache.get((dims, self))
+        if e is None:
+            e = cache[(dims, self)] = Engine(EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=1,
+                                                          max_batch=64, optimizer=self.kind, lr=float(self.learning_rate), b1=float(self.b1),
+                                                          b2=float(self.b2), eps=float(self.eps), weight_decay=float(self.weight_decay)))
+        adam = state[0]
+        p_flat = flatten(params)
+        e.set_params(p_flat, L.BUF_PARAMS); e.set_params(flatten(adam.mu), L.BUF_MU); e.set_params(flatten(adam.nu), L.BUF_NU)
+        e.set_params(flatten(grads), L.BUF_GRAD)
+        e.set_opt_count(int(adam.count))
+        e.optimizer_step()
+        new_p = e.get_params(L.BUF_PARAMS)
+        upd = Updates(unflatten(new_p - p_flat.to(new_p.device), dims))
+        upd.flat = None
+        upd.new_params = unflatten(new_p, dims)
+        new_state = (ScaleByAdamState(int(adam.count) + 1, unflatten(e.get_params(L.BUF_MU), dims), unflatten(e.get_params(L.BUF_NU), dims)),) + tuple(state[1:])
+        return upd, new_state
+
+
+_ENGINES = {}
+
+
+class Updates(dict):
+    """the `updates` pytree of GradientTransformation.update; new_params = the parameters k_adam wrote"""
+    new_params = None
+    flat = None
+
+
+def apply_updates(params, updates):
+    """optax.apply_updates (q_learning_functions.py:25): params + updates -- for an Updates object of
+    GradientTransformation.update the device pass's own result (same value, no second rounding)"""
+    if isinstance(updates, Updates) and updates.new_params is not None:
+        return updates.new_params
+    return {mod: {leaf: torch.as_tensor(params[mod][leaf]) + torch.as_tensor(u) for leaf, u in leaves.items()} for mod, leaves in updates.items()}
 
 
 def adamw(learning_rate, b1=0.9, b2=0.999, eps=1e-8, weight_decay=1e-4):

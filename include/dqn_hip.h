@@ -85,8 +85,6 @@ typedef struct {
                                * R = r_u + gamma*(r_{u+1} + gamma*(...)) cut after the first done; updates bootstrap
                                * with gamma^n_step. Rows from dqn_replay_add are stored as given. */
     int32_t flags;            /* dqn_flags, or-ed */
-    int32_t obs_time_feature; /* 1: the device-resident vector envs append step/max_steps to their observation, as ObsWrapper does
-                               * (LunarLander/env.py:19-24): obs_dim then counts the augmented width (env state = obs_dim - 1) */
 } dqn_config;
 
 const char *dqn_last_error(void);
@@ -225,6 +223,23 @@ int dqn_comm_count_host(dqn_handle *h, int32_t *ranks);   /* ncclCommCount of th
  * NaN and counts here instead of hanging the GPU. Returns the count since dqn_create (synchronises); non-zero means the
  * results since then are not to be trusted. */
 int dqn_device_errors_host(dqn_handle *h, int64_t *count);
+
+/* ---- Nature-CNN dueling Q-network, forward (BASELINE configs[4], PongNoFrameskip-v4 shape). Not in
+ * the reference: the trunk (conv 32x8x8/4, 64x4x4/2, 64x3x3/1, fc 512, ReLU) ends in the reference's dueling head
+ * (LunarLander/dddqn.py:29-31) and feeds the reference's TD rule (q_learning_functions.py:55-60). Frames: u8
+ * [B][84][84][4] (NHWC, four stacked frames), scaled by 1/255 in the first layer. Parameters, flat f32:
+ * conv1 w[8,8,4,32] b[32]  conv2 w[4,4,32,64] b[64]  conv3 w[3,3,64,64] b[64]  fc w[3136,512] b[512] (rows in [7][7][64]
+ * order)  val w[512,1] b[1]  adv w[512,A] b[A].  precision: DQN_PREC_F32 = exact f32 MFMA (k-ascending fmaf chains),
+ * DQN_PREC_BF16 = bf16 MFMA operands, f32 accumulate. Forward only in this round (no CNN backward yet). */
+typedef struct dqn_cnn_handle dqn_cnn_handle;
+int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out);
+int dqn_cnn_destroy(dqn_cnn_handle *h);
+int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n);
+int dqn_cnn_set_params(dqn_cnn_handle *h, int which_net, const float *src, int src_is_host, void *stream);
+int dqn_cnn_forward(dqn_cnn_handle *h, int which_net, const uint8_t *frames, int32_t B, float *q, void *stream);
+/* compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model: d is f32 (preprocessing :84) */
+int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
+                      const float *d, float gamma, int32_t B, float *targets, void *stream);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,12 @@ void  orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilo
  * bootstraps with gamma^n_step (f32 product gamma*gamma*...). Resets the history. */
 void  orc_learner_set_nstep(orc_learner *l, int32_t n_step, int32_t n_envs);
 
+/* ---- Nature-CNN dueling Q-network forward (dqn_oracle_cnn.c; BASELINE configs[4]; not in the reference) ----
+ * flat f32 parameters: conv1 w[8,8,4,32] b[32] conv2 w[4,4,32,64] b[64] conv3 w[3,3,64,64] b[64] fc w[3136,512] b[512]
+ * val w[512,1] b[1] adv w[512,A] b[A]; frames u8 [B][84][84][4] */
+int64_t orc_cnn_param_count(int32_t A);
+void  orc_cnn_forward(const float *P, const uint8_t *frames, int32_t B, int32_t A, float *q, float *feat);
+
 /* all-core (OpenMP) forms of the two drivers above (dqn_oracle_omp.c; one-step returns): bit-identical results, rows and
  * weight-gradient elements spread over threads. bench.py's cpu_baseline times them beside the scalar ones. */
 int32_t orc_omp_threads(void);

@@ -416,3 +416,51 @@ def cartpole_reset_states(n, seed, env_ctr):
     """fresh U(-0.05, 0.05)^4 states for all n envs at vector step env_ctr (only the done envs use theirs)"""
     o = philox_draw(seed, env_ctr, n, STREAM_ENV)
     return ((u01(o) * np.float32(0.1)).astype(np.float32) - np.float32(0.05)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ Nature-CNN dueling Q-network (BASELINE configs[4])
+# Not in the reference (SURVEY.md 8(f) rank 4): conv 32x8x8/4, 64x4x4/2, 64x3x3/1, fc 512, ReLU; the reference's dueling
+# head (LunarLander/dddqn.py:29-31). NHWC, HWIO weights, frames u8 / 255. numpy f64 = truth for tolerances.
+CNN_LAYERS = ((84, 84, 4, 20, 20, 32, 8, 8, 4), (20, 20, 32, 9, 9, 64, 4, 4, 2), (9, 9, 64, 7, 7, 64, 3, 3, 1), (1, 1, 3136, 1, 1, 512, 1, 1, 1))
+
+
+def cnn_param_count(A):
+    return sum(kh * kw * ic * oc + oc for (_, _, ic, _, _, oc, kh, kw, _) in CNN_LAYERS) + 512 + 1 + 512 * A + A
+
+
+def cnn_init_params(A, seed):
+    """haiku-style init: w ~ TruncatedNormal(1/sqrt(fan_in)) cut at 2 sigma, b = 0"""
+    rng = np.random.default_rng(seed)
+    parts = []
+    fans = [(kh * kw * ic, oc) for (_, _, ic, _, _, oc, kh, kw, _) in CNN_LAYERS] + [(512, 1), (512, A)]
+    for k, n in fans:
+        sd = 1.0 / np.sqrt(k)
+        w = np.clip(rng.standard_normal(k * n) * sd, -2 * sd, 2 * sd)
+        parts += [w, np.zeros(n)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def cnn_forward(P, frames, A, dtype=np.float64, return_feat=False):
+    """frames u8 [B,84,84,4] -> Q [B,A]"""
+    P = np.asarray(P, dtype)
+    x = np.asarray(frames).astype(dtype) / dtype(255.0)
+    o = 0
+    for (ih, iw, ic, oh, ow, oc, kh, kw, s) in CNN_LAYERS:
+        K = kh * kw * ic
+        W = P[o:o + K * oc].reshape(K, oc); o += K * oc
+        b = P[o:o + oc]; o += oc
+        B = x.shape[0]
+        x = x.reshape(B, ih, iw, ic)
+        cols = np.empty((B, oh, ow, kh, kw, ic), dtype)
+        for a in range(kh):
+            for c in range(kw):
+                cols[:, :, :, a, c, :] = x[:, a:a + s * oh:s, c:c + s * ow:s, :]
+        x = np.maximum(cols.reshape(B * oh * ow, K) @ W + b, 0).reshape(B, oh * ow * oc)
+    wv = P[o:o + 512]; o += 512
+    bv = P[o]; o += 1
+    wa = P[o:o + 512 * A].reshape(512, A); o += 512 * A
+    ba = P[o:o + A]
+    v = x @ wv + bv
+    adv = x @ wa + ba
+    q = v[:, None] + adv - adv.mean(1, keepdims=True)
+    return (q, x) if return_feat else q

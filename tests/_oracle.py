@@ -252,6 +252,16 @@ class CLearner:
         return c.value
 
 
+def cnn_forward(P, frames, A):
+    """C restatement of the Nature-CNN dueling forward (oracle/dqn_oracle_cnn.c): (q [B,A], fc features [B,512])"""
+    frames = u8(frames); B = frames.shape[0]
+    q = np.empty((B, A), np.float32); feat = np.empty((B, 512), np.float32)
+    lib().orc_cnn_param_count.restype = C.c_int64
+    assert lib().orc_cnn_param_count(C.c_int32(A)) == np.asarray(P).size
+    lib().orc_cnn_forward(_p(f32(P)), _p(frames), C.c_int32(B), C.c_int32(A), _p(q), _p(feat))
+    return q, feat
+
+
 def synth_env(n, D, seed, env_ctr, p_done):
     obs = np.empty((n, D), np.float32); r = np.empty(n, np.float32); d = np.empty(n, np.uint8)
     lib().orc_synth_env(C.c_int32(n), C.c_int32(D), C.c_uint64(seed), C.c_uint64(env_ctr), C.c_float(p_done),

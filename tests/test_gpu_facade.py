@@ -80,6 +80,34 @@ def test_factories_against_golden(ref, fn):
     assert np.array_equal(host(params.flat), z["P"])
 
 
+@pytest.mark.parametrize("kind,lr", [("adamw", 2e-4), ("adam", 1e-4)])
+def test_optimizer_update_and_apply_updates(ref, kind, lr):
+    """`updates, opt_state = optimizer.update(grads, opt_state, params)` + `optax.apply_updates` (q_learning_functions.py:
+    24-25) as separate calls: two consecutive steps bit-identical to the C oracle's Adam / AdamW on the same gradients"""
+    torch = ref["torch"]
+    dims = CFGS["cfg1"]
+    optim, unflatten = ref["optim"], ref["unflatten"]
+    opt = getattr(optim, kind)(lr)
+    rng = np.random.default_rng(4)
+    P = (onp.init_params(dims, 2) + 0.05 * rng.standard_normal(onp.param_count(*dims))).astype(np.float32)
+    params = unflatten(torch.tensor(P, device="cuda"), dims)
+    state = opt.init(params)
+    copt = oc.Opt(lr, 0.9, 0.999, 1e-8, 1e-4, int(kind == "adamw"))
+    Pc, muc, nuc, cnt, p1, p2 = P.copy(), np.zeros_like(P), np.zeros_like(P), 0, 1.0, 1.0
+    for it in range(2):
+        g = (rng.standard_normal(P.size) * 0.01).astype(np.float32)
+        grads = unflatten(torch.tensor(g, device="cuda"), dims)
+        updates, state = opt.update(grads, state, params)
+        new_params = optim.apply_updates(params, updates)
+        Pc2, muc, nuc, cnt, p1, p2 = oc.adam_step(copt, Pc, g, muc, nuc, cnt, p1, p2)
+        assert np.array_equal(host(new_params.flat), Pc2)
+        assert np.array_equal(host(state[0].mu.flat), muc) and np.array_equal(host(state[0].nu.flat), nuc) and state[0].count == it + 1
+        got_u = np.concatenate([host(updates[m][l]).reshape(-1) for m, l, _ in __import__("deep_q_learning_amd")._tree.shapes(dims)])
+        assert np.allclose(got_u, Pc2 - Pc, rtol=0, atol=1e-9)               # the updates pytree itself: new - old
+        params, Pc = new_params, Pc2
+    assert len(state) == (3 if kind == "adamw" else 2)
+
+
 @pytest.mark.parametrize("fn", ["per_L12.npz", "per_L16.npz"])
 def test_per_against_golden(ref, fn):
     z = np.load(os.path.join(GOLD, fn), allow_pickle=False)

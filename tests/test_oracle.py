@@ -264,3 +264,21 @@ def test_omp_driver_is_bit_identical_to_scalar_driver(name, B, per_on):
     for x, y in zip(runs[0][6], runs[1][6]):
         assert np.array_equal(x, y)
     assert np.array_equal(runs[0][7].view(np.uint32), runs[1][7].view(np.uint32))
+
+
+def test_cnn_oracle_c_vs_numpy_f64():
+    """Nature-CNN dueling forward (BASELINE configs[4]): the C restatement (f32 fmaf chains) against the numpy f64 one"""
+    A = 6
+    P = onp.cnn_init_params(A, 3)
+    assert P.size == onp.cnn_param_count(A)
+    rng = np.random.default_rng(4)
+    P[-A:] = rng.standard_normal(A).astype(np.float32) * 0.1            # non-zero head biases
+    frames = rng.integers(0, 256, (3, 84, 84, 4), dtype=np.uint8)
+    q, feat = oc.cnn_forward(P, frames, A)
+    q64, f64 = onp.cnn_forward(P, frames, A, np.float64, return_feat=True)
+    assert np.allclose(feat, f64, rtol=1e-5, atol=1e-5) and np.allclose(q, q64, rtol=1e-5, atol=1e-5)
+    assert np.abs(q64).max() > 1e-3 and feat.max() > 0
+    # dueling identity: mean_a Q = val  (LunarLander/dddqn.py:31)
+    o = onp.cnn_param_count(A) - (512 + 1 + 512 * A + A)
+    val = f64 @ P[o:o + 512].astype(np.float64) + P[o + 512]
+    assert np.allclose(q64.mean(1), val, rtol=1e-9, atol=1e-9)
