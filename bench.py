@@ -397,6 +397,31 @@ def per_sample_lines(dq, rank):
     return out
 
 
+def cnn_lines(dq):
+    """BASELINE.json configs[4] (PongNoFrameskip-v4 shape, 512 envs): the Nature-CNN dueling forward (dqn_cnn.hip, five
+    launches: three convolutions, fc, head) on 512 frame stacks, HIP events around 20 back-to-back forwards"""
+    out = {}
+    Bc, A_, flop = 512, 6, 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7)
+    frames = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    for prec, peak in (("bf16", MFMA_BF16_PEAK_TFLOPS), ("f32", MFMA_F32_PEAK_TFLOPS)):
+        e = dq.CnnEngine(num_actions=A_, max_batch=Bc, precision=prec)
+        e.set_params(torch.randn(e.param_count) * 0.02)
+        q = torch.empty((Bc, A_), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            e.forward(frames, out=q)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20):
+            e.forward(frames, out=q)
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        out[f"cnn_fwd_B{Bc}_{prec}"] = {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": flop * Bc / us / 1e6, "peak": peak,
+                                        "unit": "TFLOP/s", "frac": flop * Bc / us / 1e6 / peak, "traffic": None,
+                                        "note": "BASELINE configs[4] forward only (no CNN backward yet): 5 launches per forward, launch gaps included"}
+        e.close()
+    return out
+
+
 def per_sample_child():
     """per_sample_lines in a child process of its own (started, not exec'ed). The sampler at B = 2^20 is sensitive to where
     the handle's arena lands: the FIRST device allocation of a process gathers at 37-39 us, a handle created after another
@@ -648,6 +673,7 @@ def main():
             eng.close()
             out["bf16"] = quick_rate(dq, "bf16", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH))
             out["kernels"].update(per_sample_child())
+            out["kernels"].update(cnn_lines(dq))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

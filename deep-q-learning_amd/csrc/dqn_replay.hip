@@ -111,9 +111,16 @@ k_sample_uniform(const DqnState *st, const float *states, const int32_t *actions
 //     pieces, so both the ring reads (sorted leaves: neighbouring rows) and the batch writes are full-width.
 // One wave = one 64-sample chunk at a time; a workgroup walks a contiguous range of chunks (persistent grid).
 // ctr_from_state: take the Philox counter / beta from the device state (graph replay) and publish the batch max there.
+#ifndef PS_BAND
 #define PS_BAND 1024         // floats of LDS per wave for a band
+#endif
 #define PS_WIDE 256          // run width beyond which a band costs more bytes than per-lane loads
+#ifndef PS_TOPL
 #define PS_TOPL 13           // deepest level walked in the shared LDS image (64 KiB)
+#endif
+#ifndef PS_WGS_PER_CU
+#define PS_WGS_PER_CU 1      // 16-wave workgroups per CU (LDS: 4 * 2^(PS_TOPL+1) + 64 * PS_BAND bytes each)
+#endif
 
 struct PerSampleArgs {
     const DqnState *st; const float *tree; long long N; int L;
@@ -666,7 +673,7 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
     if (num_cus < 1) num_cus = 256;
     if (nchunks >= 4 * num_cus) {
         p.TL = L < PS_TOPL ? L : PS_TOPL;
-        int wgs = (nchunks + 15) / 16; if (wgs > num_cus) wgs = num_cus;
+        int wgs = (nchunks + 15) / 16; if (wgs > PS_WGS_PER_CU * num_cus) wgs = PS_WGS_PER_CU * num_cus;
         p.chunks_per_wg = (nchunks + wgs - 1) / wgs;
         wgs = (nchunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
         const size_t lds = sizeof(float) * ((size_t)(2 << p.TL) + 16 * PS_BAND);

@@ -33,8 +33,20 @@ with open(f"profiles/{rnd}_kernel_trace_one_step.csv", "w", newline="") as o:
     for r in tr[i0:i0 + 8]:
         w.writerow([r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]) - t0,
                     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"]])
-for src, dst in ((f"gpurun_out/pmc_{tag}.json", f"profiles/{rnd}_pmc.json"),
-                 (f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json")):
+import json
+pmc = json.load(open(f"gpurun_out/pmc_{tag}.json")) if os.path.exists(f"gpurun_out/pmc_{tag}.json") else {}
+if os.path.exists(f"gpurun_out/pmcs_{tag}.json"):          # the stand-alone sampler, one record per batch size
+    pmc.update(json.load(open(f"gpurun_out/pmcs_{tag}.json")))
+json.dump(pmc, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
+mf = {}
+for part in ("bench", "big"):                               # MFMA / wave-state counter passes
+    f2 = f"gpurun_out/pmcm_{tag}_{part}.json"
+    if os.path.exists(f2):
+        mf.update({k: v for k, v in json.load(open(f2)).items() if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0})
+if mf:
+    json.dump(mf, open(f"profiles/{rnd}_pmc_mfma.json", "w"), indent=1)
+for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"),
+                 (f"gpurun_out/probe_{tag}.json", f"profiles/{rnd}_per_sample_probe.json")):
     if os.path.exists(src):
         shutil.copy(src, dst)
 for s in glob.glob(f"gpurun_out/sweep_{tag}*.json"):

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (GPU box): bash tools/profile_round.sh <tag>   -- every rocprofv3 pass whose summary is committed under profiles/:
+#   kernel-trace + stats of bench.py; FETCH_SIZE / WRITE_SIZE of the bench kernels and of the stand-alone sampler (separate
+#   passes); one MFMA / wave-state counter pass for the bench kernels and one for the large-batch kernels; batch sweeps.
+tag=$1
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out
+sed -i 's/--no-cpu-baseline --profile-steps 5/--no-cpu-baseline --no-secondary --profile-steps 5/; s/--steps 200 --warmup 20 --no-cpu-baseline --profile-steps 2/--steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2/' $R/tools/prof.sh $R/tools/prof_pmc.sh
+bash $R/tools/prof.sh $tag --steps 400 --warmup 40 2>&1 | tail -12
+bash $R/tools/prof_pmc.sh $tag 2>&1 | tail -8
+bash $R/tools/prof_pmc_sample.sh $tag 2>&1 | tail -7
+bash $R/tools/prof_pmc_mfma.sh ${tag}_bench $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2 2>&1 | grep "^k_\|rc=" | cut -c1-330
+bash $R/tools/prof_pmc_mfma.sh ${tag}_big $R/tools/big_probe.py --mode update --log2 17 --reps 6 2>&1 | grep "^k_big\|rc=" | cut -c1-330
+cd $R
+python tools/per_sample_probe.py --json $out/probe_$tag.json 2>&1 | tail -8
+python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
+python tools/sweep.py --max-log2 17 --no-actor --precision bf16 --json $out/sweep_${tag}_bf16.json 2>&1 | tail -2 | cut -c1-300
