@@ -92,6 +92,7 @@ struct dqn_handle {
     int n_step = 1; float gamma_n = 0.0f;
     bool no_handover = false;                                     // DQN_FLAG_NO_HANDOVER: no in-launch waits (no sampler workgroups, k_bwd_rows on its own)
     bool no_actor16 = false, f32_actor = false;                   // DQN_FLAG_NO_ACTOR16 / DQN_FLAG_BF16_F32_ACTOR
+    bool big_any = false;                                         // DQN_FLAG_BIG_ROWS
     int tile_stride = 0;                                          // tile_cnt: [tile_stride] arrival counters + [tile_stride] consumed counts
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
@@ -116,7 +117,7 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
         if (pack == h->pack) { launch_pack(s, h->m, params, h->pack_act); launch_pack_w2k16(s, h->m, params, h->pack_act); }   // the actor kernel reads f32 shadows of the online net
     } else launch_pack(s, h->m, params, pack);
 }
-static bool use_big(dqn_handle *h, int B) { return h->big_slab != nullptr && big_supported(h->m, B); }
+static bool use_big(dqn_handle *h, int B) { return h->big_slab != nullptr && big_supported(h->m, B, h->big_any); }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
                   const BwdArgs *fuse = nullptr) {
     if (use_big(h, B) && !smp && !fuse) {                          // large batches: 64-row tiles (dqn_net_big.hip), forward only
@@ -165,7 +166,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
     REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
     REQUIRE(cfg->n_step >= 0 && cfg->n_step <= 8, "n_step %d out of range [0,8]", cfg->n_step);
-    REQUIRE((cfg->flags & ~7) == 0, "unknown flags 0x%x", cfg->flags);
+    REQUIRE((cfg->flags & ~15) == 0, "unknown flags 0x%x", cfg->flags);
     REQUIRE(cfg->n_step <= 1 || cfg->capacity >= 64ll * cfg->max_batch, "n_step > 1 needs capacity >= 64 * max_batch "
             "(the n-step actor runs in k_actor only, whose steps of one launch must fit the ring)");
 
@@ -183,6 +184,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->no_handover = (cfg->flags & DQN_FLAG_NO_HANDOVER) != 0;
     h->no_actor16 = (cfg->flags & DQN_FLAG_NO_ACTOR16) != 0;
     h->f32_actor = (cfg->flags & DQN_FLAG_BF16_F32_ACTOR) != 0;
+    h->big_any = (cfg->flags & DQN_FLAG_BIG_ROWS) != 0;
     h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
     h->gamma_n = cfg->gamma;
     for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
@@ -218,7 +220,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
-    if (!h->bf16 && big_supported(h->m, cfg->max_batch)) {
+    if (!h->bf16 && big_supported(h->m, cfg->max_batch, h->big_any)) {
         add(&h->big_slab, big_slab_floats(cfg->max_batch, h->num_cus) * 4); add(&h->big_colsum, big_colsum_floats(cfg->max_batch) * 4);
     }
     h->tile_stride = (int)(Bp / 16) + 2;

@@ -32,21 +32,22 @@ struct ConvGeom {
     float in_scale;           // u8 input: divide by this (255); else unused
 };
 
-constexpr int KC = 32;        // k-chunk
-template <typename T> struct Pad { static constexpr int v = 8; };            // LDS row = KC + pad elements: 80 B (bf16) / 160 B (f32)
+constexpr int KC = 64;        // k-chunk (a multiple of 8: an 8-element piece never crosses a patch row)
+template <typename T> struct Pad { static constexpr int v = 8; };            // LDS row = KC + pad elements
 
-__device__ __forceinline__ void cvt8(const uint8_t *p, float scale, float (&v)[8]) {
+// u8 pixels: v = (float)u8 / 255.0f, read from a 256-entry table of exactly those quotients (a division per element would
+// be ten instructions on 52 M elements per forward)
+__device__ __forceinline__ void ld8(const uint8_t *p, const float *lut, float (&v)[8]) {
     const uint2 raw = *reinterpret_cast<const uint2 *>(p);
     const uint32_t w[2] = {raw.x, raw.y};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = __fdiv_rn((float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu), scale);
+    for (int j = 0; j < 8; ++j) v[j] = lut[(w[j >> 2] >> (8 * (j & 3))) & 0xffu];
 }
-__device__ __forceinline__ void ld8(const uint8_t *p, float scale, float (&v)[8]) { cvt8(p, scale, v); }
-__device__ __forceinline__ void ld8(const float *p, float, float (&v)[8]) {
+__device__ __forceinline__ void ld8(const float *p, const float *, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-__device__ __forceinline__ void ld8(const __bf16 *p, float, float (&v)[8]) {
+__device__ __forceinline__ void ld8(const __bf16 *p, const float *, float (&v)[8]) {
     const bf16x8c a = *reinterpret_cast<const bf16x8c *>(p);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
@@ -63,23 +64,27 @@ __device__ __forceinline__ void st8(__bf16 *q, const float (&v)[8]) {
 }
 
 // TI: element type of the input tensor (uint8_t frames, or the compute type); TC: compute / weight / output type.
-// Workgroup tile: BM = 32 WM rows x BN = 32 WN columns (WM * WN = 4 waves, one 32 x 32 MFMA tile each).
+// Workgroup tile: BM = 32 WM rows x BN = 32 WN columns (WM * WN = 4 waves, one 32 x 32 MFMA tile each). The pieces of chunk
+// kc + 1 are requested into registers before chunk kc is multiplied and written to LDS behind the barrier that follows it
+// (one chunk of global latency hidden per chunk of MFMAs; several workgroups per CU hide the rest).
 template <typename TI, typename TC, int WM, int WN>
 __global__ void __launch_bounds__(256)
 k_igemm(ConvGeom g, const TI *__restrict__ in, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out, int relu) {
-    constexpr int BM = 32 * WM, BN = 32 * WN, LS = KC + Pad<TC>::v;
+    constexpr int BM = 32 * WM, BN = 32 * WN, LS = KC + Pad<TC>::v, PPR = KC / 8;      // pieces per row
     __shared__ __attribute__((aligned(16))) TC lA[BM * LS];
     __shared__ __attribute__((aligned(16))) TC lB[BN * LS];
+    __shared__ float lut[sizeof(TI) == 1 ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
     const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    if constexpr (sizeof(TI) == 1) { lut[tid] = __fdiv_rn((float)tid, g.in_scale); __syncthreads(); }
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    // this thread's share of the A image: 8-element pieces, piece q = (row q >> 2, k-offset 8 (q & 3)); BM / 64 pieces each
-    constexpr int APT = BM / 64;
+    // this thread's share of the images: 8-element pieces, piece q = (row q / PPR, k-offset 8 (q % PPR))
+    constexpr int APT = BM * PPR / 256, BPT = (BN * PPR + 255) / 256;
     long long abase[APT]; bool aon[APT];
 #pragma unroll
     for (int u = 0; u < APT; ++u) {
-        const int q = tid + 256 * u, rl = q >> 2;
+        const int q = tid + 256 * u, rl = q / PPR;
         const long long mm = m0 + rl;
         aon[u] = mm < g.M;
         const long long m2 = aon[u] ? mm : 0;
@@ -87,37 +92,44 @@ k_igemm(ConvGeom g, const TI *__restrict__ in, const TC *__restrict__ wt, const 
         const int oh = (int)(t2 % g.OH); const long long b = t2 / g.OH;
         abase[u] = ((b * g.IH + (long long)oh * g.S) * g.IW + (long long)ow * g.S) * g.IC;
     }
+    float va[APT][8], vb[BPT][8];
+    auto request = [&](int kc) {
+        const int k0 = kc * KC;
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            const int q = tid + 256 * u, kp = k0 + 8 * (q % PPR);
+            const int kh = kp / g.rowlen, rem = kp - kh * g.rowlen;
+            if (aon[u]) ld8(in + abase[u] + (long long)kh * g.IW * g.IC + rem, lut, va[u]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) va[u][j] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int q = tid + 256 * u, nl = q / PPR, ko = 8 * (q % PPR);
+            if (q < BN * PPR && n0 + nl < g.OC) ld8(wt + (long long)(n0 + nl) * g.K + k0 + ko, lut, vb[u]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vb[u][j] = 0.0f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < APT; ++u) { const int q = tid + 256 * u; st8(lA + (q / PPR) * LS + 8 * (q % PPR), va[u]); }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { const int q = tid + 256 * u; if (q < BN * PPR) st8(lB + (q / PPR) * LS + 8 * (q % PPR), vb[u]); }
+    };
     f32x16c acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int nchunks = g.K / KC;
+    request(0);
     for (int kc = 0; kc < nchunks; ++kc) {
-        const int k0 = kc * KC;
-        const int kh = k0 / g.rowlen, rem = k0 - kh * g.rowlen;
-        const long long koff = (long long)kh * g.IW * g.IC + rem;
-        // ---- stage the A chunk [BM][32] and the W chunk [BN][32]
-#pragma unroll
-        for (int u = 0; u < APT; ++u) {
-            const int q = tid + 256 * u, rl = q >> 2, ko = 8 * (q & 3);
-            float v[8];
-            if (aon[u]) ld8(in + abase[u] + koff + ko, g.in_scale, v);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-            }
-            st8(lA + rl * LS + ko, v);
-        }
-        for (int q = tid; q < BN * 4; q += 256) {
-            const int nl = q >> 2, ko = 8 * (q & 3);
-            float v[8];
-            if (n0 + nl < g.OC) ld8(wt + (long long)(n0 + nl) * g.K + k0 + ko, 1.0f, v);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-            }
-            st8(lB + nl * LS + ko, v);
-        }
+        commit();
         __syncthreads();
+        if (kc + 1 < nchunks) request(kc + 1);
         const TC *ar = lA + (32 * wm + c) * LS, *br = lB + (32 * wn + c) * LS;
         if constexpr (sizeof(TC) == 2) {
 #pragma unroll

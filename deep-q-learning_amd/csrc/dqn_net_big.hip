@@ -679,8 +679,8 @@ k_big_reduce(NetDims m, const float *__restrict__ slab, int KS, const float *__r
 }
 
 // ------------------------------------------------------------------------------- host side
-bool big_supported(const NetDims &m, int B) {
-    return B >= DQN_BIG_MIN && m.H1 == BH && m.H2 == BH && m.D <= 32 && m.A <= 15;
+bool big_supported(const NetDims &m, int B, bool any_size) {
+    return B >= (any_size ? 64 : DQN_BIG_MIN) && m.H1 == BH && m.H2 == BH && m.D <= 32 && m.A <= 15;
 }
 
 // K slices of the weight-gradient GEMM: enough workgroups to fill the machine (8 tiles x KS), at least 128 rows each

@@ -287,8 +287,15 @@ k_per_sample2(const PerSampleArgs p) {
             const long long src0 = (long long)lidx[lane >> 1] * 2 + (lane & 1), src1 = (long long)lidx[32 + (lane >> 1)] * 2 + (lane & 1);
             const float4 a0 = S4[src0], b0 = O4[src0], a1 = S4[src1], b1 = O4[src1];
             if (cn < c_end) start(cn, d);
+#ifdef PS_NT_STORES
+            typedef float nt4 __attribute__((ext_vector_type(4)));
+            auto nts = [](const float4 &v, float4 *q) { const nt4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(q)); };
+            if (lane < 2 * nrow) { nts(a0, s4 + lane); nts(b0, o4 + lane); }
+            if (lane + 64 < 2 * nrow) { nts(a1, s4 + lane + 64); nts(b1, o4 + lane + 64); }
+#else
             if (lane < 2 * nrow) { s4[lane] = a0; o4[lane] = b0; }
             if (lane + 64 < 2 * nrow) { s4[lane + 64] = a1; o4[lane + 64] = b1; }
+#endif
         } else {
             if ((D & 3) == 0) {
                 const int C = D >> 2, tot = nrow * C;                // 16-byte pieces of this chunk's rows
@@ -312,7 +319,12 @@ k_per_sample2(const PerSampleArgs p) {
             }
             if (cn < c_end) start(cn, d);
         }
+#ifdef PS_NT_STORES
+        if (in_range) { __builtin_nontemporal_store((int32_t)leaf, p.idx + k); __builtin_nontemporal_store(w_is, p.w_raw + k); __builtin_nontemporal_store(av, p.a + k);
+                        __builtin_nontemporal_store(rv, p.r + k); __builtin_nontemporal_store(dv, p.d + k); }
+#else
         if (in_range) { p.idx[k] = (int32_t)leaf; p.w_raw[k] = w_is; p.a[k] = av; p.r[k] = rv; p.d[k] = dv; }
+#endif
         c = cn;
     }
     STAMP(3, 2);

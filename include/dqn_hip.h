@@ -55,7 +55,9 @@ typedef enum {
                                     * The library takes this path by itself where the device (CU count) cannot hold the
                                     * co-resident grids; the flag forces it (tests). Same results, bit for bit. */
     DQN_FLAG_NO_ACTOR16 = 2,       /* never the 16-env small-net actor kernel */
-    DQN_FLAG_BF16_F32_ACTOR = 4    /* bf16 mode with the exact-f32 actor chain */
+    DQN_FLAG_BF16_F32_ACTOR = 4,   /* bf16 mode with the exact-f32 actor chain */
+    DQN_FLAG_BIG_ROWS = 8          /* take the 64-row large-batch kernels (dqn_net_big.hip; 2x256 nets, f32) for every batch of
+                                    * >= 64 rows instead of from 16 384 rows up (tests: same results at small sizes) */
 } dqn_flags;
 
 typedef struct dqn_handle dqn_handle;

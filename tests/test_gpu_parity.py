@@ -39,11 +39,14 @@ def rand_params(dims, seed):
 
 # ------------------------------------------------------------------------- forward
 @pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg1", 1), ("cfg1", 37), ("cfg2", 1024), ("cfg3", 8192), ("cfg2", 100),
-                                    ("cfg2", 8200)])          # 8200 rows of the 2x256 net: the 64-row kernels (dqn_net_big.hip), ragged last tile
+                                    ("cfg2", 16400), ("cfg2", -200), ("cfg2", -64)])
 def test_forward_parity(dq, name, B):
-    """Model.__call__ (LunarLander/dddqn.py:24-34)"""
+    """Model.__call__ (LunarLander/dddqn.py:24-34). 16 400 rows of the 2x256 net take the 64-row kernels (dqn_net_big.hip),
+    ragged last tile; B < 0: those kernels forced at |B| rows (DQN_FLAG_BIG_ROWS)"""
     dims = CFGS[name]
-    e = mk(dq, dims, max_batch=B)
+    big = B < 0
+    B = abs(B)
+    e = mk(dq, dims, max_batch=B, flags=dq._lib.FLAG_BIG_ROWS if big else 0)
     P, Pt = rand_params(dims, 0), rand_params(dims, 1)
     e.set_params(P); e.set_params(Pt, dq._lib.BUF_TARGET)
     x = np.random.default_rng(2).standard_normal((B, dims[0])).astype(np.float32)
@@ -63,11 +66,14 @@ def test_forward_parity(dq, name, B):
 
 
 # ------------------------------------------------------------------------- targets
-@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 512), ("cfg2", 8200)])
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 512), ("cfg2", -1000)])
 def test_q_targets_parity(dq, name, B):
-    """compute_q_targets (q_learning_functions.py:42-64) incl. quirks Q3/Q4 and argmax ties"""
+    """compute_q_targets (q_learning_functions.py:42-64) incl. quirks Q3/Q4 and argmax ties (B < 0: the 64-row kernels of
+    dqn_net_big.hip forced at |B| rows)"""
     dims = CFGS[name]
-    e = mk(dq, dims, max_batch=B)
+    big = B < 0
+    B = abs(B)
+    e = mk(dq, dims, max_batch=B, flags=dq._lib.FLAG_BIG_ROWS if big else 0)
     P, Pt = rand_params(dims, 3), rand_params(dims, 4)
     P[onp.param_count(*dims) - dims[3]:] = 0.0           # ba = 0 -> exact ties possible on the s2=0 row
     e.set_params(P); e.set_params(Pt, dq._lib.BUF_TARGET)
@@ -92,12 +98,15 @@ def test_q_targets_parity(dq, name, B):
 
 
 # ----------------------------------------------------------------- loss / gradients
-@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 8192), ("cfg1", 50), ("cfg2", 8200), ("cfg2", 16384)])
+@pytest.mark.parametrize("name,B", [("cfg1", 64), ("cfg2", 1024), ("cfg3", 8192), ("cfg1", 50), ("cfg2", -1000), ("cfg2", -100), ("cfg2", 16400)])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_loss_and_grads_parity(dq, name, B, weighted):
-    """compute_loss (:31-39) and jax.grad(compute_loss) (:23)"""
+    """compute_loss (:31-39) and jax.grad(compute_loss) (:23). 16 400 rows of cfg2 / B < 0 (forced at |B| rows): one workgroup
+    per 64-row tile does forward + row backward, split-K weight gradients (dqn_net_big.hip)"""
     dims = CFGS[name]
-    e = mk(dq, dims, max_batch=B)
+    big = B < 0
+    B = abs(B)
+    e = mk(dq, dims, max_batch=B, flags=dq._lib.FLAG_BIG_ROWS if big else 0)
     P, Pt = rand_params(dims, 7), rand_params(dims, 8)
     e.set_params(P)
     s, a, r, s2, d = make_batch(dims, B, 9)
@@ -322,7 +331,7 @@ def test_act_parity(dq):
 
 # ------------------------------------------------------------------ the fused update
 @pytest.mark.parametrize("name,B,per", [("cfg1", 64, False), ("cfg1", 64, True), ("cfg2", 1024, True), ("cfg3", 2048, True),
-                                        ("cfg2", 8200, True), ("cfg2", 8192, False)])      # >= 8192 rows of the 2x256 net: dqn_net_big.hip
+                                        ("cfg2", -1000, True), ("cfg2", -1024, False), ("cfg2", 16400, True)])   # B < 0 / 16 400 rows: dqn_net_big.hip
 def test_fused_update_tracks_oracle(dq, name, B, per):
     """Agent._step (q_agent.py:146-169) as dqn_update_fused, 4 consecutive updates (graph replays) with a
     target sync in between, against the C oracle's whole-update driver on the same replay contents.
@@ -332,8 +341,10 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
     D, A = dims[0], dims[3]
     L_ = 12
     N = 1 << L_
-    lr = 1e-3 if B < 8192 else 2e-4          # (8 192-row sums: two f32 summation orders differ by ~1e-5 * lr / 1e-3 after the optimizer; the reference's lr)
-    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=lr)
+    big = B < 0                              # the 64-row kernels forced at |B| rows (DQN_FLAG_BIG_ROWS)
+    B = abs(B)
+    lr = 1e-3 if B < 8192 else 2e-4          # (16 400-row sums: two f32 summation orders differ by ~1e-5 * lr / 1e-3 after the optimizer; the reference's lr)
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=lr, flags=dq._lib.FLAG_BIG_ROWS if big else 0)
     cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
     s, a, r, s2, d = make_batch(dims, 3000, 70, terminal_frac=0.1)
     r = np.clip(r, -2, 2)
@@ -350,7 +361,7 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
         # (two lock-step trajectories stay index-identical only while no stratified draw falls within rounding distance of
         # a priority boundary: with 8 200 draws per update that is a matter of a few updates -- seen at the third -- so the
         # large batches are compared over two updates)
-        n_it = 4 if B < 8192 else 2
+        n_it = 4 if (B < 8192 and not big) else 2           # (the 64-row kernels sum the batch in another order than the restatement: two updates)
         for it in range(n_it):
             Lc = lrn.update(B)
             e.update(B)
