@@ -65,6 +65,7 @@ SIGNATURES = {
     "dqn_set_epsilon": [_P, _F, _P],
     "dqn_env_config": [_P, _I32, _I32, _F],
     "dqn_env_stats_host": [_P, C.POINTER(_I64), C.POINTER(_I64)],
+    "dqn_env_time_feature": [_P, _I32],
     "dqn_env_reset": [_P, _P, _I32, _F, _P],
     "dqn_actor_step": [_P, _I32, _P],
     "dqn_actor_steps": [_P, _I32, _I32, _P],

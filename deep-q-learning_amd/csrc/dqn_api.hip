@@ -96,6 +96,7 @@ struct dqn_handle {
     int tile_stride = 0;                                          // tile_cnt: [tile_stride] arrival counters + [tile_stride] consumed counts
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
+    bool env_time_feature = false;                                // the last observation column is ObsWrapper's step / max_steps
     // per-kernel HIP-event timing (dqn_profile_*): events[i] .. events[i+1] brackets launch i
     bool profiling = false;
     std::vector<hipEvent_t> events; size_t ev_used = 0;
@@ -392,7 +393,7 @@ extern "C" int dqn_per_sample(dqn_handle *h, int32_t B, float beta, uint64_t see
     HIP_TRY(hipMemsetAsync(h->wmax_tmp, 0, 4, st));
     arm(h);
     launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations,
-                      h->dones, h->cfg.obs_dim, B, beta, seed, ctr, 0, s, a, r, s2, d, idx, h->bw_raw, h->wmax_tmp, h->num_cus);
+                      h->dones, h->cfg.obs_dim, B, beta, seed, ctr, 0, s, a, r, s2, d, idx, h->bw_raw, h->wmax_tmp, h->num_cus, true);
     mark(h, st, "per_sample");
     launch_isw_normalize(st, h->bw_raw, B, isw, h->st, h->wmax_tmp);
     HIP_TRY(hipGetLastError());
@@ -556,7 +557,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
             arm(h);
             launch_per_sample(st, h->st, h->tree, h->Ntree, h->L, h->states, h->actions, h->rewards, h->observations, h->dones,
                               h->cfg.obs_dim, B, 0.0f, h->cfg.seed, 0, 1, h->bs, h->ba, h->br, h->bs2, h->bd, h->bidx, h->bw_raw,
-                              reinterpret_cast<unsigned int *>(&h->st->wmax), h->num_cus);
+                              reinterpret_cast<unsigned int *>(&h->st->wmax), h->num_cus, false);
             mark(h, st, "per_sample");
         } else {
             launch_sample_uniform(st, h->st, h->states, h->actions, h->rewards, h->observations, h->dones, h->cfg.obs_dim, B,
@@ -662,6 +663,7 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
 // resident in registers, the T*n new leaves inserted by a side workgroup, and -- presample_B > 0 -- the stratified PER
 // draw of the update that follows done by further side workgroups once the leaves are in.
 static bool actor_multi_ok(dqn_handle *h, int n_envs, int T) {
+    if (h->env_time_feature) return false;                        // the time-fraction pass runs behind every vector step: enqueue_actor
     return T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
 }
 static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
@@ -684,6 +686,9 @@ static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
 // env transition + ring insert per 4-env workgroup, leaves inserted by the tree workgroup)
 static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuild_top = false) {
     enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0);
+    if (h->env_time_feature)                                      // LunarLander/env.py:19-24 for the vector envs (dqn_env_time_feature)
+        launch_env_time_feature(st, h->st, h->observations, h->dones, h->env_obs, h->env_t, h->cfg.capacity, h->cfg.obs_dim, n_envs,
+                                h->env_max_steps);
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only). body_err: set non-zero by a body
@@ -766,8 +771,18 @@ extern "C" int dqn_env_config(dqn_handle *h, int32_t kind, int32_t max_steps, fl
     REQUIRE(kind == DQN_ENV_SYNTHETIC || kind == DQN_ENV_CARTPOLE, "unknown env kind %d", kind);
     REQUIRE(kind != DQN_ENV_CARTPOLE || (h->cfg.obs_dim == 4 && h->cfg.num_actions == 2), "CartPole needs obs_dim 4, num_actions 2");
     REQUIRE(max_steps >= 1, "max_steps must be >= 1");
+    REQUIRE(!(h->env_time_feature && kind != DQN_ENV_SYNTHETIC), "the time-fraction feature is built for the synthetic env only");
     h->env_kind = kind; h->env_max_steps = max_steps; h->env_term_reward = term_reward;
     destroy_graphs(h);                                           // env parameters are baked into captured launches
+    return DQN_OK;
+}
+
+extern "C" int dqn_env_time_feature(dqn_handle *h, int32_t enable) {
+    REQUIRE(h, "null argument");
+    REQUIRE(!enable || (h->env_kind == DQN_ENV_SYNTHETIC && h->n_step <= 1 && h->cfg.obs_dim >= 2),
+            "the time-fraction feature is built for the synthetic vector env with one-step returns (obs_dim counts the feature)");
+    h->env_time_feature = enable != 0;
+    destroy_graphs(h);
     return DQN_OK;
 }
 

@@ -143,7 +143,10 @@ struct PsChunk {
     float2 pc[PS_BAND / 128];
 };
 
-template <int WAVES>
+// NT: the batch is written with non-temporal stores (the caller consumes it in a later launch at the earliest: keeping 85 MB of
+// output out of the L2 / Infinity Cache leaves them to the ring -- 34.5 instead of 37.3 us at B = 2^20); the large-batch update,
+// whose forward reads the rows right away, takes the plain form
+template <int WAVES, bool NT>
 __global__ void __launch_bounds__(WAVES * 64)
 k_per_sample2(const PerSampleArgs p) {
     extern __shared__ __attribute__((aligned(16))) float ps_lds[];
@@ -287,15 +290,15 @@ k_per_sample2(const PerSampleArgs p) {
             const long long src0 = (long long)lidx[lane >> 1] * 2 + (lane & 1), src1 = (long long)lidx[32 + (lane >> 1)] * 2 + (lane & 1);
             const float4 a0 = S4[src0], b0 = O4[src0], a1 = S4[src1], b1 = O4[src1];
             if (cn < c_end) start(cn, d);
-#ifdef PS_NT_STORES
-            typedef float nt4 __attribute__((ext_vector_type(4)));
-            auto nts = [](const float4 &v, float4 *q) { const nt4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(q)); };
-            if (lane < 2 * nrow) { nts(a0, s4 + lane); nts(b0, o4 + lane); }
-            if (lane + 64 < 2 * nrow) { nts(a1, s4 + lane + 64); nts(b1, o4 + lane + 64); }
-#else
-            if (lane < 2 * nrow) { s4[lane] = a0; o4[lane] = b0; }
-            if (lane + 64 < 2 * nrow) { s4[lane + 64] = a1; o4[lane + 64] = b1; }
-#endif
+            if constexpr (NT) {
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                auto nts = [](const float4 &v, float4 *q) { const nt4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(q)); };
+                if (lane < 2 * nrow) { nts(a0, s4 + lane); nts(b0, o4 + lane); }
+                if (lane + 64 < 2 * nrow) { nts(a1, s4 + lane + 64); nts(b1, o4 + lane + 64); }
+            } else {
+                if (lane < 2 * nrow) { s4[lane] = a0; o4[lane] = b0; }
+                if (lane + 64 < 2 * nrow) { s4[lane + 64] = a1; o4[lane + 64] = b1; }
+            }
         } else {
             if ((D & 3) == 0) {
                 const int C = D >> 2, tot = nrow * C;                // 16-byte pieces of this chunk's rows
@@ -319,12 +322,12 @@ k_per_sample2(const PerSampleArgs p) {
             }
             if (cn < c_end) start(cn, d);
         }
-#ifdef PS_NT_STORES
-        if (in_range) { __builtin_nontemporal_store((int32_t)leaf, p.idx + k); __builtin_nontemporal_store(w_is, p.w_raw + k); __builtin_nontemporal_store(av, p.a + k);
-                        __builtin_nontemporal_store(rv, p.r + k); __builtin_nontemporal_store(dv, p.d + k); }
-#else
-        if (in_range) { p.idx[k] = (int32_t)leaf; p.w_raw[k] = w_is; p.a[k] = av; p.r[k] = rv; p.d[k] = dv; }
-#endif
+        if (in_range) {
+            if constexpr (NT) {
+                __builtin_nontemporal_store((int32_t)leaf, p.idx + k); __builtin_nontemporal_store(w_is, p.w_raw + k); __builtin_nontemporal_store(av, p.a + k);
+                __builtin_nontemporal_store(rv, p.r + k); __builtin_nontemporal_store(dv, p.d + k);
+            } else { p.idx[k] = (int32_t)leaf; p.w_raw[k] = w_is; p.a[k] = av; p.r[k] = rv; p.d[k] = dv; }
+        }
         c = cn;
     }
     STAMP(3, 2);
@@ -647,6 +650,34 @@ k_per_add(const DqnState *st, float *tree, long long Nt, int L, int n, long long
 }
 
 
+// ----------------------------------------------- ObsWrapper's time-fraction feature for the vector envs
+// LunarLander/env.py:19-24: the observation handed to the agent is append(obs, step / max_steps) (python float division,
+// then float32), `step` pre-incremented by step() and zeroed by reset(); q_agent.py:179-180 ends the episode at max_steps.
+// The device-resident vector envs keep that feature as the LAST observation column. This pass runs right behind a
+// one-step actor launch (which treated the column like any other): for env i, whose transition went to ring slot
+// (ring_counter - n + i) % capacity, it writes the next observation's feature, folds the step limit into `done`, and sets
+// the env's current feature (0 after an episode end: reset()) and step counter.
+__global__ void __launch_bounds__(256)
+k_env_time_feature(const DqnState *st, float *observations, uint8_t *dones, float *env_obs, int32_t *env_t, long long cap,
+                   int D, int n, int max_steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c0 = st->ring_counter - (unsigned long long)n;
+    const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)cap);
+    const int tt = env_t[i] + 1;                                                   // env.py:24
+    const bool done = dones[k] != 0 || tt >= max_steps;                           // q_agent.py:179-180
+    const float f = (float)((double)tt / (double)max_steps);                      // env.py:20
+    observations[k * D + D - 1] = f;
+    dones[k] = done ? 1 : 0;
+    env_obs[(long long)i * D + D - 1] = done ? 0.0f : f;                          // env.py:28-30: reset() -> step 0
+    env_t[i] = done ? 0 : tt;
+}
+
+void launch_env_time_feature(hipStream_t st_, const DqnState *st, float *observations, uint8_t *dones, float *env_obs,
+                             int32_t *env_t, long long cap, int D, int n, int max_steps) {
+    hipLaunchKernelGGL(k_env_time_feature, dim3((n + 255) / 256), dim3(256), 0, st_, st, observations, dones, env_obs, env_t, cap, D, n, max_steps);
+}
+
 // --------------------------------------------------------------------- launchers
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
                        float *observations, uint8_t *dones, long long N, int D, const float *s,
@@ -678,7 +709,7 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        const float *observations, const uint8_t *dones, int D, int B, float beta,
                        unsigned long long seed, unsigned long long ctr, int from_state,
                        float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw,
-                       unsigned int *wmax_bits, int num_cus) {
+                       unsigned int *wmax_bits, int num_cus, bool nt_out) {
     PerSampleArgs p{st, tree, N, L, states, actions, rewards, observations, dones, D, B, beta, seed, ctr, from_state,
                     s, a, r, s2, d, idx, w_raw, wmax_bits, 0, 1};
     const int nchunks = (B + 63) / 64;
@@ -689,10 +720,11 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
         p.chunks_per_wg = (nchunks + wgs - 1) / wgs;
         wgs = (nchunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
         const size_t lds = sizeof(float) * ((size_t)(2 << p.TL) + 16 * PS_BAND);
-        DQN_LAUNCH((k_per_sample2<16>), dim3(wgs), dim3(1024), lds, st_, p);
+        if (nt_out) DQN_LAUNCH((k_per_sample2<16, true>), dim3(wgs), dim3(1024), lds, st_, p);
+        else DQN_LAUNCH((k_per_sample2<16, false>), dim3(wgs), dim3(1024), lds, st_, p);
     } else {
         p.TL = 0; p.chunks_per_wg = 1;
-        DQN_LAUNCH((k_per_sample2<1>), dim3(nchunks), dim3(64), sizeof(float) * PS_BAND, st_, p);
+        DQN_LAUNCH((k_per_sample2<1, false>), dim3(nchunks), dim3(64), sizeof(float) * PS_BAND, st_, p);
     }
 }
 

@@ -325,6 +325,10 @@ class Engine:
         L.check(self.lib.dqn_env_config(self.h, {"synthetic": L.ENV_SYNTHETIC, "cartpole": L.ENV_CARTPOLE}[kind],
                                         int(max_steps), float(term_reward)))
 
+    def env_time_feature(self, enable=True):
+        """ObsWrapper's step / max_steps feature (LunarLander/env.py:19-24) as the last observation column of the vector envs"""
+        L.check(self.lib.dqn_env_time_feature(self.h, int(bool(enable))))
+
     def env_stats(self):
         """(finished episodes, summed episode length) of the device-resident envs; synchronises"""
         ep, st = C.c_int64(), C.c_int64()

@@ -189,6 +189,13 @@ int dqn_set_epsilon(dqn_handle *h, float epsilon, void *stream);
  * of finished episodes and their summed length (synchronises). */
 int dqn_env_config(dqn_handle *h, int32_t kind, int32_t max_steps, float term_reward);
 int dqn_env_stats_host(dqn_handle *h, int64_t *episodes, int64_t *episode_steps);
+/* ObsWrapper (LunarLander/env.py:19-31) for the device-resident vector envs: with enable != 0 the LAST observation column
+ * (obs_dim counts it: 8 + 1 = 9 as in the reference) is step / max_steps -- float32 of the float64 quotient, `step`
+ * pre-incremented by every env step and zeroed when an episode ends -- and an episode also ends at max_steps
+ * (q_agent.py:179-180; max_steps from dqn_env_config). Synthetic env, one-step returns; the vector steps between two
+ * updates then run as separate launches with the feature pass behind each. dqn_env_reset's observations carry the
+ * feature of step 0 (0.0) in that column. */
+int dqn_env_time_feature(dqn_handle *h, int32_t enable);
 int dqn_env_reset(dqn_handle *h, const float *obs, int32_t n_envs, float p_done, void *stream);
 int dqn_actor_step(dqn_handle *h, int32_t n_envs, void *stream);
 /* env_steps consecutive vector env steps (q_agent.py:176-183 x train_frequency, between two updates the parameters do

@@ -133,6 +133,10 @@ float orc_learner_update(orc_learner *l, int32_t B);
 /* q_agent.py:176-183 for n envs: act (epsilon-greedy) -> synthetic transition -> replay.add (+PER leaf) ->
  * state = observation. obs is [n,D] and is advanced in place; *env_ctr is incremented. */
 void  orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon, float p_done, uint64_t *env_ctr);
+/* the same with ObsWrapper's step / max_steps feature (LunarLander/env.py:19-31) as the last observation column; t[n] = the
+ * envs' step counters, advanced in place */
+void  orc_learner_actor_step_tf(orc_learner *l, float *obs, int32_t *t, int32_t n, float epsilon, float p_done, int32_t max_steps,
+                                uint64_t *env_ctr);
 /* n-step returns for the vector actor: every env keeps its last n_step (s, a, r, done); from the (n_step)-th step after
  * this call on, each vector step adds ONE row per env: (s_u, a_u, R, s_{t+1}, done_n) for the window u = t-n_step+1 .. t,
  * R = r_u + gamma*(r_{u+1} + gamma*(...)) cut after the first done in the window (done_n = 1 then). The update then

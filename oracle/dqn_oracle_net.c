@@ -386,3 +386,32 @@ void orc_learner_actor_step(orc_learner *l, float *obs, int32_t n, float epsilon
     *env_ctr += 1;
     free(a); free(slots); free(next); free(r); free(d);
 }
+
+/* The vector actor step with ObsWrapper's feature (LunarLander/env.py:19-31) as the last observation column: obs[n,D] holds the
+ * current observations incl. the feature, t[n] the envs' step counters (both advanced in place). Per env: the synthetic
+ * transition as orc_learner_actor_step (the draw of the last column is unused), next[D-1] = float32(float64(t + 1) / max_steps)
+ * (env.py:20, :24), done |= t + 1 >= max_steps (q_agent.py:179-180); the row goes to the ring; the env continues from `next`,
+ * after an episode end with feature 0 and t = 0 (env.py:28-30). One-step returns. */
+void orc_learner_actor_step_tf(orc_learner *l, float *obs, int32_t *t, int32_t n, float epsilon, float p_done, int32_t max_steps,
+                               uint64_t *env_ctr) {
+    const int32_t D = l->m.D;
+    int32_t *a = (int32_t *)malloc(sizeof(int32_t) * n), *slots = (int32_t *)malloc(sizeof(int32_t) * n);
+    float *next = (float *)malloc(sizeof(float) * (size_t)n * D), *r = (float *)malloc(sizeof(float) * n);
+    uint8_t *d = (uint8_t *)malloc(n);
+    orc_act(l->m, l->P, obs, n, epsilon, l->seed, *env_ctr, a);                 /* q_agent.py:176 */
+    orc_synth_env(n, D, l->seed, *env_ctr, p_done, next, r, d);                  /* :177 (synthetic) */
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t tt = t[i] + 1;                                            /* env.py:24 */
+        next[(int64_t)i * D + D - 1] = (float)((double)tt / (double)max_steps); /* env.py:20 */
+        if (tt >= max_steps) d[i] = 1;                                          /* q_agent.py:179-180 */
+    }
+    orc_replay_add(l->rb, obs, a, r, next, d, n, slots);                         /* :182 */
+    if (l->per) orc_per_add(l->per, slots, n);
+    memcpy(obs, next, sizeof(float) * (size_t)n * D);                            /* :183 */
+    for (int32_t i = 0; i < n; ++i) {
+        if (d[i]) { obs[(int64_t)i * D + D - 1] = 0.0f; t[i] = 0; }             /* env.py:28-30 */
+        else t[i] = t[i] + 1;
+    }
+    *env_ctr += 1;
+    free(a); free(slots); free(next); free(r); free(d);
+}

@@ -244,6 +244,13 @@ class CLearner:
         """n-step returns for the vector actor (orc_learner_set_nstep); resets the history"""
         lib().orc_learner_set_nstep(C.byref(self.l), C.c_int32(n_step), C.c_int32(n_envs))
 
+    def actor_step_tf(self, obs, t, epsilon, p_done, max_steps, env_ctr):
+        """vector step with ObsWrapper's time-fraction feature as the last column; obs and t advance in place"""
+        c = C.c_uint64(env_ctr)
+        lib().orc_learner_actor_step_tf(C.byref(self.l), _p(obs), _p(t), C.c_int32(obs.shape[0]), C.c_float(epsilon),
+                                        C.c_float(p_done), C.c_int32(max_steps), C.byref(c))
+        return c.value
+
     def actor_step(self, obs, epsilon, p_done, env_ctr):
         """advances obs in place; returns the new env counter"""
         c = C.c_uint64(env_ctr)

@@ -417,6 +417,77 @@ def test_actor_step_bitexact(dq, per):
     e.close()
 
 
+@pytest.mark.parametrize("dims,n,max_steps,per", [((9, 32, 64, 4), 37, 5, True), ((9, 256, 256, 4), 256, 7, True), ((9, 32, 64, 4), 64, 1500, False)])
+def test_actor_time_feature_bitexact(dq, dims, n, max_steps, per):
+    """ObsWrapper (LunarLander/env.py:19-31) for the device-resident vector envs (dqn_env_time_feature): the last observation
+    column is float32(float64(step) / max_steps), `step` pre-incremented per env step and zeroed at an episode end, and an
+    episode also ends at max_steps (q_agent.py:179-180). Ring, env observations, step counters, tree and the captured
+    training loop's rows against the restatement, bit for bit, over several truncations (max_steps 5 / 7) and ring wraps;
+    the feature values themselves against orc_obs_augment."""
+    import ctypes as C
+    import torch
+    D = dims[0]
+    L_ = 11; N = 1 << L_
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=max(n, 64), seed=33)
+    e.env_config("synthetic", max_steps, 1.0)
+    e.env_time_feature(True)
+    cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
+    P0 = rand_params(dims, 82)
+    e.set_params(P0)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, 64, cr, ct, P0, 33)
+    obs = np.random.default_rng(83).standard_normal((n, D)).astype(np.float32)
+    obs[:, D - 1] = 0.0                                                     # reset(): step 0
+    t = np.zeros(n, np.int32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.3)
+    ctr = 0
+    steps = 13
+    seen = set()
+    with torch.cuda.stream(e.stream):
+        for it in range(steps):
+            ctr = lrn.actor_step_tf(obs, t, 0.3, 0.05, max_steps, ctr)
+            seen.update(np.unique(t).tolist())
+            if it % 3 == 2:
+                e.actor_steps(1)                                            # the multi-step entry point falls back to single steps
+            else:
+                e.actor_step()
+        e.stream.synchronize()
+    L = dq._lib
+    assert e.replay_size() == (cr.size, cr.rb.counter)
+    got = (e.buffer(L.BUF_STATES).view(N, D), e.buffer(L.BUF_ACTIONS, torch.int32), e.buffer(L.BUF_REWARDS),
+           e.buffer(L.BUF_OBSERVATIONS).view(N, D), e.buffer(L.BUF_DONES, torch.uint8))
+    for x, y in zip(got, cr.arrays()):
+        assert np.array_equal(host(x), y)
+    assert np.array_equal(host(e.buffer(L.BUF_ENV_OBS))[: n * D].reshape(n, D), obs)
+    if per:
+        assert np.array_equal(host(e.buffer(L.BUF_TREE)), ct.tree)
+    # the feature is exactly what the reference's wrapper computes
+    rows = min(cr.size, N)
+    nxt = cr.arrays()[3][:rows, D - 1]
+    stepno = np.rint(nxt.astype(np.float64) * max_steps).astype(np.int32)
+    aug = np.empty((rows, 2), np.float32)
+    oc.lib().orc_obs_augment(oc._p(np.zeros((rows, 1), np.float32)), oc._p(stepno), C.c_int32(max_steps), C.c_int32(rows), C.c_int32(1), oc._p(aug))
+    assert np.array_equal(aug[:, 1], nxt) and stepno.min() >= 1 and stepno.max() <= max_steps
+    if max_steps < steps:
+        assert (cr.arrays()[4][:rows][stepno == max_steps] == 1).all() and (stepno == max_steps).sum() > 0      # truncation -> done
+        assert 0 in seen
+    # the captured training loop (q_agent.py:174-187) keeps the feature consistent: every stored next-observation carries
+    # k / max_steps for an integer 1 <= k <= max_steps, a row with k = max_steps is terminal, the current observations carry
+    # their envs' step counters
+    with torch.cuda.stream(e.stream):
+        for _ in range(3):
+            e.train_iters(2, 4, 64)
+        e.stream.synchronize()
+    size = e.replay_size()[0]
+    nx = host(e.buffer(L.BUF_OBSERVATIONS).view(N, D))[:size, D - 1].astype(np.float64) * max_steps
+    kk = np.rint(nx)
+    assert np.all(np.abs(nx - kk) < 1e-3) and kk.min() >= 1 and kk.max() <= max_steps
+    assert np.all(host(e.buffer(L.BUF_DONES, torch.uint8))[:size][kk == max_steps] == 1)
+    cur = host(e.buffer(L.BUF_ENV_OBS))[: n * D].reshape(n, D)[:, D - 1].astype(np.float64) * max_steps
+    assert np.all(np.abs(cur - np.rint(cur)) < 1e-3) and cur.min() >= 0 and cur.max() < max_steps
+    assert e.opt_count() == 6 and np.isfinite(float(e.last_loss().item())) and e.device_errors() == 0
+    e.close()
+
+
 @pytest.mark.parametrize("dims,n,T,L_,per", [
     ((9, 32, 64, 4), 37, 3, 8, True),        # ragged last tile (37 = 9*4 + 1), small net classes, wraps a 256-slot ring
     ((9, 32, 64, 4), 37, 3, 8, False),       # uniform replay: no tree workgroup
