@@ -44,6 +44,18 @@ class VectorAgent:
         engine.sync_target()
         self.updates = 0
 
+    def inject(self, gamma, epsilon, epsilon_decay_rate, min_epsilon, replace_frequency, batch_size, train_frequency):
+        """ParamAgent.inject (General/QLearning/hyperparameter_optimization.py:76-91) for the device-resident loop: the seven
+        searched hyper-parameters are replaced between two training runs. gamma is baked into the captured launches
+        (dqn_set_gamma drops them), epsilon lives on the device, batch size / train frequency select the loop graph."""
+        self.e.set_gamma(float(gamma))
+        self.epsilon, self.decay, self.min_eps = float(epsilon), float(epsilon_decay_rate), float(min_epsilon)
+        self.e.set_epsilon(self.epsilon)
+        self.replace_frequency, self.train_frequency = int(replace_frequency), int(train_frequency)
+        if int(batch_size) > self.e.cfg.max_batch:
+            raise ValueError(f"batch_size {batch_size} exceeds the engine's max_batch {self.e.cfg.max_batch}")
+        self.B = int(batch_size)
+
     def _mean_return(self, ep0, st0, ep1, st1):
         return (st1 - st0) / (ep1 - ep0) if ep1 > ep0 else float("nan")
 

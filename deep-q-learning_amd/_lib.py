@@ -43,6 +43,7 @@ SIGNATURES = {
     "dqn_get_opt_count_host": [_P, C.POINTER(_I32)],
     "dqn_buffer": [_P, C.c_int, C.POINTER(_P), C.POINTER(_I64)],
     "dqn_set_schedule": [_P, _F, _F, _P],
+    "dqn_set_gamma": [_P, _F],
     "dqn_replay_add": [_P, _P, _P, _P, _P, _P, _I32, _P],
     "dqn_replay_size_host": [_P, C.POINTER(_I64), C.POINTER(_I64)],
     "dqn_replay_sample_uniform": [_P, _I32, _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -349,6 +349,17 @@ extern "C" int dqn_set_schedule(dqn_handle *h, float per_beta, float lr, void *s
     return DQN_OK;
 }
 
+/* gamma is a by-value argument of the captured launches (and gamma^n_step is derived from it): changing it drops the graphs */
+extern "C" int dqn_set_gamma(dqn_handle *h, float gamma) {
+    REQUIRE(h && gamma >= 0.0f && gamma <= 1.0f, "dqn_set_gamma: gamma out of [0, 1]");
+    if (gamma == h->cfg.gamma) return DQN_OK;
+    h->cfg.gamma = gamma;
+    h->gamma_n = gamma;
+    for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * gamma;
+    destroy_graphs(h);
+    return DQN_OK;
+}
+
 // ------------------------------------------------------------------------------ replay
 extern "C" int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, const float *r,
                               const float *s2, const uint8_t *d, int32_t n, void *stream) {

@@ -178,6 +178,11 @@ class Engine:
             self.cfg.lr = lr
         L.check(self.lib.dqn_set_schedule(self.h, self.cfg.per_beta, self.cfg.lr, self._s()))
 
+    def set_gamma(self, gamma):
+        """discount of the TD rule (q_learning_functions.py:58) for the handle's own update; captured graphs are rebuilt"""
+        self.cfg.gamma = float(gamma)
+        L.check(self.lib.dqn_set_gamma(self.h, float(gamma)))
+
     def sync_target(self):
         L.check(self.lib.dqn_sync_target(self.h, self._s()))
 

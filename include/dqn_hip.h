@@ -107,6 +107,10 @@ int dqn_set_opt_count(dqn_handle *h, int32_t count, void *stream);   /* ScaleByA
 int dqn_get_opt_count_host(dqn_handle *h, int32_t *count);           /* synchronises */
 int dqn_buffer(dqn_handle *h, int which, void **ptr, int64_t *nbytes);
 int dqn_set_schedule(dqn_handle *h, float per_beta, float lr, void *stream);
+/* re-parameterisation between training runs (ParamAgent.inject, General/QLearning/hyperparameter_optimization.py:76-91):
+ * gamma is baked into captured launches, so the handle's graphs are dropped and re-captured on next use. epsilon:
+ * dqn_set_epsilon; batch size / train frequency: arguments of dqn_train_iters (one graph per combination). */
+int dqn_set_gamma(dqn_handle *h, float gamma);
 
 /* ReplayBuffer.add (replay_buffer.py:58-65), vectorised: n rows at consecutive slots
  * counter % capacity. With use_per the new leaves get the running max priority. */

@@ -382,6 +382,41 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
     e.close()
 
 
+def test_gamma_injection_rebuilds_graphs(dq):
+    """ParamAgent.inject (General/QLearning/hyperparameter_optimization.py:76-91) on the device loop: gamma is baked into the
+    captured update; dqn_set_gamma drops the graphs, and the next (re-captured) update must use the new discount -- checked
+    against the restatement's driver with its gamma switched at the same point"""
+    import torch
+    dims = CFGS["cfg1"]
+    D = dims[0]
+    L_ = 10; N = 1 << L_
+    B = 64
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=41, lr=1e-3, gamma=0.99)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    s, a, r, s2, d = make_batch(dims, 900, 90, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    ct.add(cr.add(s, a, r, s2, d > 0)); e.replay_add(s, a, r, s2, d > 0)
+    P0 = rand_params(dims, 91)
+    e.set_params(P0); e.set_params(P0, dq._lib.BUF_TARGET)
+    lrn = oc.CLearner(dims, oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), 0.99, B, cr, ct, P0, 41, beta=0.4)
+    with torch.cuda.stream(e.stream):
+        for it in range(4):
+            if it == 2:
+                e.set_gamma(0.9); lrn.l.gamma = 0.9
+            Lc = lrn.update(B); e.update(B); e.stream.synchronize()
+            assert abs(host(e.last_loss())[0] - Lc) <= 2e-5 * max(1.0, abs(Lc)), it
+    assert np.max(np.abs(e.get_params(host=True) - lrn.params)) <= 1e-5
+    # and it did change something: the same four updates without the switch end elsewhere
+    e2 = mk(dq, dims, capacity=N, use_per=True, max_batch=B, seed=41, lr=1e-3, gamma=0.99)
+    e2.replay_add(s, a, r, s2, d > 0); e2.set_params(P0); e2.set_params(P0, dq._lib.BUF_TARGET)
+    with torch.cuda.stream(e2.stream):
+        for it in range(4):
+            e2.update(B)
+        e2.stream.synchronize()
+    assert np.max(np.abs(e2.get_params(host=True) - e.get_params(host=True))) > 1e-6
+    e.close(); e2.close()
+
+
 # ----------------------------------------------------------------- synthetic actor
 @pytest.mark.parametrize("per", [False, True])
 def test_actor_step_bitexact(dq, per):

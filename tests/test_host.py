@@ -131,6 +131,20 @@ def test_optimizer_state_shapes_like_optax():
     assert st[0].mu["model/~/linear_1"]["w"].shape == (32, 64)
 
 
+def test_param_agent_inject_mirrors_the_reference():
+    """General/QLearning/hyperparameter_optimization.py:76-91: inject rebinds the seven searched hyper-parameters; as in the
+    reference the q-target closure built in the constructor keeps its gamma unless rebuild_closures is asked for"""
+    from deep_q_learning_amd.General.QLearning.hyperparameter_optimization import ParamAgent
+    a = ParamAgent.__new__(ParamAgent)                      # no device needed for the attribute semantics
+    a._compute_q_targets = sentinel = object()
+    a.inject(0.95, 0.8, 0.97, 0.05, 30, 48, 3)
+    assert (a._gamma, a._epsilon, a._epsilon_decay_rate, a._min_epsilon, a._replace_frequency, a._batch_size, a._train_frequency) == \
+        (0.95, 0.8, 0.97, 0.05, 30, 48, 3)
+    assert a._compute_q_targets is sentinel
+    a.max_episodes = 7
+    assert a.max_episodes == 7 and a._max_episodes == 7
+
+
 def test_transform_finds_the_model():
     from deep_q_learning_amd.LunarLander.dddqn import Model, transform, without_apply_rng
     m = without_apply_rng(transform(lambda *args: Model(4)(*args)))     # Test/lunar_lander.py:47
