@@ -25,169 +25,256 @@
 typedef float f32x16c __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 
-struct ConvGeom {
-    int IH, IW, IC, OH, OW, OC, KH, KW, S;
-    int K, rowlen;            // K = KH*KW*IC, rowlen = KW*IC (contiguous elements of a patch row)
-    long long M;              // B*OH*OW
-    float in_scale;           // u8 input: divide by this (255); else unused
-};
+// Geometry of the four GEMM layers, compile-time (every index division below folds into shifts / multiplies), with the tile
+// shape chosen per layer: workgroup tile = (MT*WM) rows x (MT*WN) columns, one MT x MT MFMA tile per wave (4 waves), and R =
+// depth of the register prefetch ring (R divides the chunk count K / 64).
+//   conv1  M = 400 B, K = 256 (4 chunks),  N = 32   128 x 32 tile, everything requested up front
+//   conv2  M =  81 B, K = 512 (8),         N = 64    64 x 64
+//   conv3  M =  49 B, K = 576 (9),         N = 64    64 x 64
+//   fc     M =      B, K = 3136 (49),      N = 512   32 x 32 from 16 x 16 MFMA tiles: at B = 512 that is 256 workgroups, and in
+//          f32 mode the k-ascending chain of 16x16x4 is 784 MFMAs x 32 cycles (the 32x32x2 chain would be 1568 x 64)
+template <int L> struct CnnGeo;
+template <> struct CnnGeo<0> { static constexpr int IH = 84, IW = 84, IC = 4, OH = 20, OW = 20, OC = 32, KH = 8, KW = 8, S = 4, MT = 32, WM = 4, WN = 1, R = 4; };
+template <> struct CnnGeo<1> { static constexpr int IH = 20, IW = 20, IC = 32, OH = 9, OW = 9, OC = 64, KH = 4, KW = 4, S = 2, MT = 32, WM = 2, WN = 2, R = 4; };
+template <> struct CnnGeo<2> { static constexpr int IH = 9, IW = 9, IC = 64, OH = 7, OW = 7, OC = 64, KH = 3, KW = 3, S = 1, MT = 32, WM = 2, WN = 2, R = 3; };
+template <> struct CnnGeo<3> { static constexpr int IH = 1, IW = 1, IC = 3136, OH = 1, OW = 1, OC = 512, KH = 1, KW = 1, S = 1, MT = 16, WM = 2, WN = 2, R = 7; };
 
 constexpr int KC = 64;        // k-chunk (a multiple of 8: an 8-element piece never crosses a patch row)
-template <typename T> struct Pad { static constexpr int v = 8; };            // LDS row = KC + pad elements
+constexpr int CNN_F = 512;    // fc width = the heads' K
 
-// u8 pixels: v = (float)u8 / 255.0f, read from a 256-entry table of exactly those quotients (a division per element would
-// be ten instructions on 52 M elements per forward)
-__device__ __forceinline__ void ld8(const uint8_t *p, const float *lut, float (&v)[8]) {
-    const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+// 8 consecutive k of one image row, as loaded (raw) and as committed to LDS (compute type)
+template <typename T> struct RawPiece;
+template <> struct RawPiece<uint8_t> { typedef uint2 t; };
+template <> struct RawPiece<__bf16> { typedef bf16x8c t; };
+struct f32x8raw { float4 a, b; };
+template <> struct RawPiece<float> { typedef f32x8raw t; };
+
+template <typename T> __device__ __forceinline__ typename RawPiece<T>::t load_piece(const T *p) {
+    return *reinterpret_cast<const typename RawPiece<T>::t *>(p);
+}
+// u8 pixels: v = (float)u8 / 255.0f, read from a 256-entry LDS table of exactly those quotients
+__device__ __forceinline__ void piece_f32(const uint2 &raw, const float *lut, float (&v)[8]) {
     const uint32_t w[2] = {raw.x, raw.y};
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = lut[(w[j >> 2] >> (8 * (j & 3))) & 0xffu];
 }
-__device__ __forceinline__ void ld8(const float *p, const float *, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+__device__ __forceinline__ void piece_f32(const f32x8raw &raw, const float *, float (&v)[8]) {
+    v[0] = raw.a.x; v[1] = raw.a.y; v[2] = raw.a.z; v[3] = raw.a.w; v[4] = raw.b.x; v[5] = raw.b.y; v[6] = raw.b.z; v[7] = raw.b.w;
 }
-__device__ __forceinline__ void ld8(const __bf16 *p, const float *, float (&v)[8]) {
-    const bf16x8c a = *reinterpret_cast<const bf16x8c *>(p);
+__device__ __forceinline__ void piece_f32(const bf16x8c &raw, const float *, float (&v)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+    for (int j = 0; j < 8; ++j) v[j] = (float)raw[j];
 }
-__device__ __forceinline__ void st8(float *q, const float (&v)[8]) {
-    *reinterpret_cast<float4 *>(q) = float4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<float4 *>(q + 4) = float4{v[4], v[5], v[6], v[7]};
-}
-__device__ __forceinline__ void st8(__bf16 *q, const float (&v)[8]) {
-    bf16x8c a;
+// LDS image of a 64-deep chunk of one row. bf16: k in order (a lane's MFMA operand = 8 consecutive k = one 16-byte read).
+// f32: k permuted so that the k a lane feeds to consecutive MFMAs are consecutive words (16-byte reads again):
+//   32x32x2 (lane half h takes k = 2s + h):  position (k & 1) * 32 + (k >> 1)
+//   16x16x4 (lane group g takes k = 4s + g): position (k & 3) * 16 + (k >> 2)
+// bf16 mode keeps the pixels as the integers 0..255 (exact in bf16: v_cvt_f32_ubyte + pack, no table) and folds the 1/255
+// into conv1's weight shadow (k_cnn_pack with scale 255).
+template <int MT, typename TR>
+__device__ __forceinline__ void commit_piece(__bf16 *row, int j, const TR &raw, const float *) {
+    if constexpr (__is_same(TR, bf16x8c)) *reinterpret_cast<bf16x8c *>(row + 8 * j) = raw;
+    else {
+        static_assert(__is_same(TR, uint2), "bf16 layers read u8 frames or bf16 activations");
+        const uint32_t w[2] = {raw.x, raw.y};
+        bf16x8c a;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
-    *reinterpret_cast<bf16x8c *>(q) = a;
+        for (int i = 0; i < 8; ++i) a[i] = (__bf16)(float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        *reinterpret_cast<bf16x8c *>(row + 8 * j) = a;
+    }
+}
+template <int MT, typename TR>
+__device__ __forceinline__ void commit_piece(float *row, int j, const TR &raw, const float *lut) {
+    float v[8]; piece_f32(raw, lut, v);
+    if constexpr (MT == 32) {
+        *reinterpret_cast<float4 *>(row + 4 * j) = float4{v[0], v[2], v[4], v[6]};
+        *reinterpret_cast<float4 *>(row + 32 + 4 * j) = float4{v[1], v[3], v[5], v[7]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float2 *>(row + 16 * i + 2 * j) = float2{v[i], v[4 + i]};
+    }
 }
 
 // TI: element type of the input tensor (uint8_t frames, or the compute type); TC: compute / weight / output type.
-// Workgroup tile: BM = 32 WM rows x BN = 32 WN columns (WM * WN = 4 waves, one 32 x 32 MFMA tile each). The pieces of chunk
-// kc + 1 are requested into registers before chunk kc is multiplied and written to LDS behind the barrier that follows it
-// (one chunk of global latency hidden per chunk of MFMAs; several workgroups per CU hide the rest).
-template <typename TI, typename TC, int WM, int WN>
+// The loop over k-chunks is a software pipeline: chunk kc + R is requested into the register slot chunk kc has just left (R
+// chunks of global latency in flight per thread), the LDS image is double-buffered (one barrier per chunk; conv1, four chunks all requested
+// up front, keeps a single buffer and more workgroups per CU). All slot indices are compile-time, so every s_waitcnt counts the loads of
+// the newer slots instead of draining the queue. Workgroups are numbered so that the ones an XCD receives (id mod 8) are
+// neighbours in m (shared patch rows / weight columns stay in that XCD's L2).
+template <typename TI, typename TC, int L>
 __global__ void __launch_bounds__(256)
-k_igemm(ConvGeom g, const TI *__restrict__ in, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out, int relu) {
-    constexpr int BM = 32 * WM, BN = 32 * WN, LS = KC + Pad<TC>::v, PPR = KC / 8;      // pieces per row
-    __shared__ __attribute__((aligned(16))) TC lA[BM * LS];
-    __shared__ __attribute__((aligned(16))) TC lB[BN * LS];
-    __shared__ float lut[sizeof(TI) == 1 ? 256 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    if constexpr (sizeof(TI) == 1) { lut[tid] = __fdiv_rn((float)tid, g.in_scale); __syncthreads(); }
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    // this thread's share of the images: 8-element pieces, piece q = (row q / PPR, k-offset 8 (q % PPR))
-    constexpr int APT = BM * PPR / 256, BPT = (BN * PPR + 255) / 256;
-    long long abase[APT]; bool aon[APT];
+k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out) {
+    typedef CnnGeo<L> G;
+    constexpr int MT = G::MT, WM = G::WM, WN = G::WN, R = G::R;
+    constexpr int BM = MT * WM, BN = MT * WN, K = G::KH * G::KW * G::IC, ROWLEN = G::KW * G::IC, NCH = K / KC, NIT = NCH / R;
+    constexpr int LS = KC + (sizeof(TC) == 2 ? 8 : 4);
+    constexpr int LBUF = L == 0 ? 1 : 2;
+    constexpr int APT = BM * 8 / 256, BPT = BN * 8 / 256;
+    static_assert(WM * WN == 4 && K % KC == 0 && NCH % R == 0 && G::OC % BN == 0 && ROWLEN % 8 == 0 && APT >= 1 && BPT >= 1, "tile shape");
+    typedef typename RawPiece<TI>::t RA;
+    typedef typename RawPiece<TC>::t RB;
+    __shared__ __attribute__((aligned(16))) TC lA[LBUF * BM * LS];
+    __shared__ __attribute__((aligned(16))) TC lB[LBUF * BN * LS];
+    __shared__ float lut[(sizeof(TI) == 1 && sizeof(TC) == 4) ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) lut[tid] = __fdiv_rn((float)tid, 255.0f);          // barrier below, behind the first requests
+    constexpr int NT = G::OC / BN;
+    const int mtiles = (M + BM - 1) / BM, total = mtiles * NT;
+    int t = blockIdx.x;
+    if ((total & 7) == 0) t = (t & 7) * (total >> 3) + (t >> 3);
+    const int m0 = (t / NT) * BM, n0 = (t % NT) * BN;
+    const int pj = tid & 7;                                                            // this thread's k-piece within a row
+    const TI *ap[APT]; const TC *bp[BPT];
 #pragma unroll
     for (int u = 0; u < APT; ++u) {
-        const int q = tid + 256 * u, rl = q / PPR;
-        const long long mm = m0 + rl;
-        aon[u] = mm < g.M;
-        const long long m2 = aon[u] ? mm : 0;
-        const int ow = (int)(m2 % g.OW); const long long t2 = m2 / g.OW;
-        const int oh = (int)(t2 % g.OH); const long long b = t2 / g.OH;
-        abase[u] = ((b * g.IH + (long long)oh * g.S) * g.IW + (long long)ow * g.S) * g.IC;
+        int mm = m0 + (tid >> 3) + 32 * u;
+        mm = mm < M ? mm : M - 1;                                                      // rows past the end: a valid row, never stored
+        const unsigned ow = (unsigned)mm % G::OW, t2 = (unsigned)mm / G::OW, oh = t2 % G::OH, b = t2 / G::OH;
+        ap[u] = in + ((long long)(b * G::IH + oh * G::S) * G::IW + ow * G::S) * G::IC;
     }
-    float va[APT][8], vb[BPT][8];
-    auto request = [&](int kc) {
-        const int k0 = kc * KC;
 #pragma unroll
-        for (int u = 0; u < APT; ++u) {
-            const int q = tid + 256 * u, kp = k0 + 8 * (q % PPR);
-            const int kh = kp / g.rowlen, rem = kp - kh * g.rowlen;
-            if (aon[u]) ld8(in + abase[u] + (long long)kh * g.IW * g.IC + rem, lut, va[u]);
-            else {
+    for (int u = 0; u < BPT; ++u) bp[u] = wt + (long long)(n0 + (tid >> 3) + 32 * u) * K + 8 * pj;
+    RA ra[R][APT]; RB rb[R][BPT];
+    auto request = [&](int slot, int kc) {
+        const int kp = kc * KC + 8 * pj, kh = kp / ROWLEN, rem = kp - kh * ROWLEN, koff = kh * (G::IW * G::IC) + rem;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) va[u][j] = 0.0f;
-            }
-        }
+        for (int u = 0; u < APT; ++u) ra[slot][u] = load_piece<TI>(ap[u] + koff);
 #pragma unroll
-        for (int u = 0; u < BPT; ++u) {
-            const int q = tid + 256 * u, nl = q / PPR, ko = 8 * (q % PPR);
-            if (q < BN * PPR && n0 + nl < g.OC) ld8(wt + (long long)(n0 + nl) * g.K + k0 + ko, lut, vb[u]);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vb[u][j] = 0.0f;
-            }
-        }
+        for (int u = 0; u < BPT; ++u) rb[slot][u] = load_piece<TC>(bp[u] + kc * KC);
     };
-    auto commit = [&]() {
+    auto commit = [&](int slot, int buf) {
+        TC *a = lA + buf * (BM * LS) + (tid >> 3) * LS, *b = lB + buf * (BN * LS) + (tid >> 3) * LS;
 #pragma unroll
-        for (int u = 0; u < APT; ++u) { const int q = tid + 256 * u; st8(lA + (q / PPR) * LS + 8 * (q % PPR), va[u]); }
+        for (int u = 0; u < APT; ++u) commit_piece<MT>(a + 32 * u * LS, pj, ra[slot][u], lut);
 #pragma unroll
-        for (int u = 0; u < BPT; ++u) { const int q = tid + 256 * u; if (q < BN * PPR) st8(lB + (q / PPR) * LS + 8 * (q % PPR), vb[u]); }
+        for (int u = 0; u < BPT; ++u) commit_piece<MT>(b + 32 * u * LS, pj, rb[slot][u], lut);
     };
-    f32x16c acc;
+    typedef float accv __attribute__((ext_vector_type(MT == 32 ? 16 : 4)));
+    accv acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const int nchunks = g.K / KC;
-    request(0);
-    for (int kc = 0; kc < nchunks; ++kc) {
-        commit();
-        __syncthreads();
-        if (kc + 1 < nchunks) request(kc + 1);
-        const TC *ar = lA + (32 * wm + c) * LS, *br = lB + (32 * wn + c) * LS;
-        if constexpr (sizeof(TC) == 2) {
+    for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[r] = 0.0f;
+    const int hi = lane / MT, c = lane % MT;                                           // MT = 32: half h; MT = 16: k-group g
+    auto multiply = [&](int buf) {
+        const TC *ar = lA + buf * (BM * LS) + (MT * wm + c) * LS, *br = lB + buf * (BN * LS) + (MT * wn + c) * LS;
+        if constexpr (sizeof(TC) == 2 && MT == 32) {
 #pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks) {
-                const bf16x8c a = *reinterpret_cast<const bf16x8c *>(ar + 16 * ks + 8 * h);
-                const bf16x8c b = *reinterpret_cast<const bf16x8c *>(br + 16 * ks + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            for (int ks = 0; ks < KC / 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8c *>(ar + 16 * ks + 8 * hi),
+                                                              *reinterpret_cast<const bf16x8c *>(br + 16 * ks + 8 * hi), acc, 0, 0, 0);
+        } else if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < KC / 32; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8c *>(ar + 32 * ks + 8 * hi),
+                                                              *reinterpret_cast<const bf16x8c *>(br + 32 * ks + 8 * hi), acc, 0, 0, 0);
+        } else if constexpr (MT == 32) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                                               // k = 2 (4q + i) + h: ascending chain
+                const float4 a = *reinterpret_cast<const float4 *>(ar + 32 * hi + 4 * q), b = *reinterpret_cast<const float4 *>(br + 32 * hi + 4 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < KC / 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s + h], br[2 * s + h], acc, 0, 0, 0);   // k = 2s, then 2s + 1: ascending chain
-        }
-        __syncthreads();
-    }
-    const int n = n0 + 32 * wn + c;
-    if (n < g.OC) {
-        const float bv = bias[n];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long mm = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (mm < g.M) {
-                float v = acc[r] + bv;
-                if (relu) v = v > 0.0f ? v : 0.0f;
-                out[mm * g.OC + n] = (TC)v;
+            for (int q = 0; q < 4; ++q) {                                               // k = 4 (4q + i) + g: ascending chain
+                const float4 a = *reinterpret_cast<const float4 *>(ar + 16 * hi + 4 * q), b = *reinterpret_cast<const float4 *>(br + 16 * hi + 4 * q);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
             }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r) request(r, r);
+    if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) __syncthreads();                 // the table, before the first commit reads it
+#pragma unroll                      // fully: a rolled loop turns the ring into register copies that wait for the loads just issued
+    for (int it = 0; it < NIT - 1; ++it) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int kc = it * R + r, buf = LBUF == 2 ? (kc & 1) : 0;
+            commit(r, buf);
+            request(r, kc + R);
+            __syncthreads();
+            multiply(buf);
+            if constexpr (LBUF == 1) __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int kc = (NIT - 1) * R + r, buf = LBUF == 2 ? (kc & 1) : 0;
+        commit(r, buf);
+        __syncthreads();
+        multiply(buf);
+        if constexpr (LBUF == 1) __syncthreads();
+    }
+    const int n = n0 + MT * wn + c;
+    const float bv = bias[n];
+#pragma unroll
+    for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) {
+        const int mm = m0 + MT * wm + (MT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * hi : 4 * hi + r);
+        if (mm < M) {
+            float v = acc[r] + bv;
+            v = v > 0.0f ? v : 0.0f;
+            out[(long long)mm * G::OC + n] = (TC)v;
         }
     }
 }
 
-// dueling head (dddqn.py:29-31) on the fc features [B][F]: one thread per row; val / adv are k-ascending fmaf chains
-// (f32 weights [F][1 + A]: column 0 = val, 1.. = adv), Q = val + adv - mean(adv)
+// dueling head (dddqn.py:29-31) on the fc features [B][512]: 16 rows per workgroup, thread (row, j) runs the k-ascending fmaf
+// chain of output j (0 = val, 1.. = adv) from LDS images of the rows and of the j-major head weights [16][512];
+// Q = val + adv - mean(adv) with the restatement's order of additions.
 template <typename TC>
-__global__ void __launch_bounds__(64)
-k_cnn_head(const TC *__restrict__ feat, int F, const float *__restrict__ wh, const float *__restrict__ bh, int A, int B, float *q) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= B) return;
-    float acc[16];
-    for (int j = 0; j <= A; ++j) acc[j] = 0.0f;
-    const TC *x = feat + (long long)i * F;
-    for (int k = 0; k < F; ++k) {
-        const float xv = (float)x[k];
-        for (int j = 0; j <= A; ++j) acc[j] = fmaf(xv, wh[(long long)k * (A + 1) + j], acc[j]);
+__global__ void __launch_bounds__(256)
+k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const float *__restrict__ bh, int A, int B, float *q) {
+    constexpr int LS = CNN_F + 4;
+    __shared__ __attribute__((aligned(16))) float lx[16 * LS];
+    __shared__ __attribute__((aligned(16))) float lw[16 * LS];
+    __shared__ float lo[16 * 16];
+    const int tid = threadIdx.x, r0 = blockIdx.x * 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                                       // 16 rows x 64 pieces of 8
+        const int p = tid + 256 * u, row = p >> 6, j = p & 63;
+        int i = r0 + row; i = i < B ? i : B - 1;
+        float v[8]; piece_f32(load_piece<TC>(feat + (long long)i * CNN_F + 8 * j), nullptr, v);
+        *reinterpret_cast<float4 *>(lx + row * LS + 8 * j) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4 *>(lx + row * LS + 8 * j + 4) = float4{v[4], v[5], v[6], v[7]};
     }
-    float sum = 0.0f;
-    for (int j = 1; j <= A; ++j) { acc[j] = acc[j] + bh[j]; sum = sum + acc[j]; }
-    const float v = acc[0] + bh[0], mean = __fdiv_rn(sum, (float)A);
-    for (int j = 0; j < A; ++j) q[(long long)i * A + j] = (v + acc[1 + j]) - mean;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                                                       // 16 outputs x 128 float4
+        const int p = tid + 256 * u, j = p >> 7, k4 = p & 127;
+        *reinterpret_cast<float4 *>(lw + j * LS + 4 * k4) = *reinterpret_cast<const float4 *>(wht + j * CNN_F + 4 * k4);
+    }
+    __syncthreads();
+    const int row = tid >> 4, j = tid & 15;
+    const float *x = lx + row * LS, *w = lw + j * LS;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int k4 = 0; k4 < CNN_F / 4; ++k4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + 4 * k4), wv = *reinterpret_cast<const float4 *>(w + 4 * k4);
+        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+    }
+    lo[tid] = j <= A ? acc + bh[j] : 0.0f;
+    __syncthreads();
+    const int i = r0 + row;
+    if (j < A && i < B) {
+        float sum = 0.0f;
+        for (int a = 1; a <= A; ++a) sum = sum + lo[16 * row + a];
+        const float mean = __fdiv_rn(sum, (float)A);
+        q[(long long)i * A + j] = (lo[16 * row] + lo[16 * row + 1 + j]) - mean;
+    }
 }
 
 // flat f32 parameters -> transposed compute-type shadow [N][K]
 template <typename TC>
 __global__ void __launch_bounds__(256)
-k_cnn_pack(const float *__restrict__ w, int K, int N, TC *__restrict__ wt) {
+k_cnn_pack(const float *__restrict__ w, int K, int N, float div, TC *__restrict__ wt) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)K * N) return;
     const int n = (int)(t / K), k = (int)(t - (long long)n * K);
-    wt[t] = (TC)w[(long long)k * N + n];
+    const float v = w[(long long)k * N + n];
+    wt[t] = (TC)(div != 1.0f ? __fdiv_rn(v, div) : v);
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -201,23 +288,16 @@ struct dqn_cnn_handle {
     void *arena = nullptr;
     float *params[2] = {nullptr, nullptr};             // online, target (flat f32, HWIO leaf order)
     void *wt[2][4] = {{nullptr}};                      // transposed shadows of the four GEMM layers
-    float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads [512][1 + A], biases [1 + A]
+    float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads, output-major [16][512] (0 = val, 1.. = adv), biases [1 + A]
     void *act[4] = {nullptr};                          // layer outputs
     float *q[3] = {nullptr, nullptr, nullptr};         // Q of the three passes of compute_q_targets
     float *scratch = nullptr;
 };
 
-static const int CNN_IH = 84, CNN_IC = 4;
-static ConvGeom cnn_geom(int layer, long long B) {
-    ConvGeom g{};
-    switch (layer) {
-    case 0: g = ConvGeom{84, 84, 4, 20, 20, 32, 8, 8, 4, 0, 0, 0, 255.0f}; break;
-    case 1: g = ConvGeom{20, 20, 32, 9, 9, 64, 4, 4, 2, 0, 0, 0, 1.0f}; break;
-    case 2: g = ConvGeom{9, 9, 64, 7, 7, 64, 3, 3, 1, 0, 0, 0, 1.0f}; break;
-    default: g = ConvGeom{1, 1, 3136, 1, 1, 512, 1, 1, 1, 0, 0, 0, 1.0f}; break;
-    }
-    g.K = g.KH * g.KW * g.IC; g.rowlen = g.KW * g.IC; g.M = B * g.OH * g.OW;
-    return g;
+struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
+template <int L> static LayerShape shape_of() { typedef CnnGeo<L> G; return LayerShape{G::KH * G::KW * G::IC, G::OC, G::OH * G::OW}; }
+static LayerShape cnn_shape(int layer) {
+    switch (layer) { case 0: return shape_of<0>(); case 1: return shape_of<1>(); case 2: return shape_of<2>(); default: return shape_of<3>(); }
 }
 
 extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out) {
@@ -228,7 +308,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     h->A = num_actions; h->max_batch = max_batch; h->bf16 = precision == DQN_PREC_BF16;
     long long p = 0;
     for (int l = 0; l < 4; ++l) {
-        const ConvGeom g = cnn_geom(l, 1);
+        const LayerShape g = cnn_shape(l);
         h->L[l] = CnnLayer{g.K, g.OC, p, p + (long long)g.K * g.OC};
         p += (long long)g.K * g.OC + g.OC;
     }
@@ -236,8 +316,8 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     const size_t esz = h->bf16 ? 2 : 4;
     size_t total = 0;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    size_t sz_params = al(h->P * 4), sz_wt[4], sz_act[4], sz_wh = al(512 * (h->A + 1) * 4), sz_bh = al((h->A + 1) * 4), sz_q = al((size_t)max_batch * h->A * 4);
-    for (int l = 0; l < 4; ++l) { sz_wt[l] = al((size_t)h->L[l].K * h->L[l].N * esz); sz_act[l] = al((size_t)cnn_geom(l, max_batch).M * h->L[l].N * esz); }
+    size_t sz_params = al(h->P * 4), sz_wt[4], sz_act[4], sz_wh = al(16 * CNN_F * 4), sz_bh = al((h->A + 1) * 4), sz_q = al((size_t)max_batch * h->A * 4);
+    for (int l = 0; l < 4; ++l) { sz_wt[l] = al((size_t)h->L[l].K * h->L[l].N * esz); sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz); }
     total = 2 * sz_params + 2 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + sz_act[0] + sz_act[1] + sz_act[2] + sz_act[3] + 3 * sz_q + al((size_t)max_batch * 4);
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
@@ -271,11 +351,9 @@ extern "C" int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n) {
 
 __global__ void __launch_bounds__(256)
 k_cnn_pack_head(const float *__restrict__ P, long long o_wv, long long o_bv, long long o_wa, long long o_ba, int A, float *wh, float *bh) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < 512 * (A + 1)) {
-        const int k = t / (A + 1), j = t - k * (A + 1);
-        wh[t] = j == 0 ? P[o_wv + k] : P[o_wa + (long long)k * A + (j - 1)];
-    }
+    const int t = blockIdx.x * 256 + threadIdx.x;                  // grid covers 16 * 512
+    const int j = t / CNN_F, k = t - j * CNN_F;
+    wh[t] = j == 0 ? P[o_wv + k] : (j <= A ? P[o_wa + (long long)k * A + (j - 1)] : 0.0f);
     if (t <= A) bh[t] = t == 0 ? P[o_bv] : P[o_ba + t - 1];
 }
 
@@ -288,30 +366,31 @@ extern "C" int dqn_cnn_set_params(dqn_cnn_handle *h, int which, const float *src
     for (int l = 0; l < 4; ++l) {
         const long long n = (long long)h->L[l].K * h->L[l].N;
         const int blocks = (int)((n + 255) / 256);
-        if (h->bf16) hipLaunchKernelGGL((k_cnn_pack<__bf16>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, (__bf16 *)h->wt[which][l]);
-        else hipLaunchKernelGGL((k_cnn_pack<float>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, (float *)h->wt[which][l]);
+        if (h->bf16) hipLaunchKernelGGL((k_cnn_pack<__bf16>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, l == 0 ? 255.0f : 1.0f, (__bf16 *)h->wt[which][l]);
+        else hipLaunchKernelGGL((k_cnn_pack<float>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, 1.0f, (float *)h->wt[which][l]);
     }
-    hipLaunchKernelGGL(k_cnn_pack_head, dim3((512 * (h->A + 1) + 255) / 256), dim3(256), 0, s, h->params[which], h->o_wv, h->o_bv, h->o_wa, h->o_ba, h->A, h->wh[which], h->bh[which]);
+    hipLaunchKernelGGL(k_cnn_pack_head, dim3(16 * CNN_F / 256), dim3(256), 0, s, h->params[which], h->o_wv, h->o_bv, h->o_wa, h->o_ba, h->A, h->wh[which], h->bh[which]);
     CNN_TRY(hipGetLastError());
     if (src_is_host) CNN_TRY(hipStreamSynchronize(s));
     return DQN_OK;
 }
 
-template <typename TI, typename TC, int WM, int WN>
-static void launch_igemm(hipStream_t s, const ConvGeom &g, const TI *in, const TC *wt, const float *bias, TC *out, int relu) {
-    const dim3 grid((unsigned)((g.M + 32 * WM - 1) / (32 * WM)), (unsigned)((g.OC + 32 * WN - 1) / (32 * WN)));
-    DQN_LAUNCH((k_igemm<TI, TC, WM, WN>), grid, dim3(256), 0, s, g, in, wt, bias, out, relu);
+template <typename TI, typename TC, int L>
+static void launch_layer(hipStream_t s, int B, const TI *in, const TC *wt, const float *bias, TC *out) {
+    typedef CnnGeo<L> G;
+    const int M = B * G::OH * G::OW, BM = G::MT * G::WM, BN = G::MT * G::WN;
+    DQN_LAUNCH((k_cnn_layer<TI, TC, L>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
 }
 
 template <typename TC>
 static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B, float *q, hipStream_t s) {
     const float *P = h->params[which];
     TC *a0 = (TC *)h->act[0], *a1 = (TC *)h->act[1], *a2 = (TC *)h->act[2], *a3 = (TC *)h->act[3];
-    launch_igemm<uint8_t, TC, 4, 1>(s, cnn_geom(0, B), frames, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0, 1);
-    launch_igemm<TC, TC, 2, 2>(s, cnn_geom(1, B), a0, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1, 1);
-    launch_igemm<TC, TC, 2, 2>(s, cnn_geom(2, B), a1, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2, 1);
-    launch_igemm<TC, TC, 2, 2>(s, cnn_geom(3, B), a2, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3, 1);
-    hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 63) / 64), dim3(64), 0, s, a3, 512, h->wh[which], h->bh[which], h->A, B, q);
+    launch_layer<uint8_t, TC, 0>(s, B, frames, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
+    launch_layer<TC, TC, 1>(s, B, a0, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
+    launch_layer<TC, TC, 2>(s, B, a1, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
+    launch_layer<TC, TC, 3>(s, B, a2, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3);
+    hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
