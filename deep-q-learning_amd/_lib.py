@@ -85,6 +85,13 @@ SIGNATURES = {
     "dqn_cnn_set_params": [_P, C.c_int, _P, C.c_int, _P],
     "dqn_cnn_forward": [_P, C.c_int, _P, _I32, _P, _P],
     "dqn_cnn_q_targets": [_P, _P, _P, _P, _P, _P, _F, _I32, _P, _P],
+    "dqn_cnn_grads": [_P, _P, _P, _P, _I32, _P, _P],
+    "dqn_cnn_get_buffer": [_P, C.c_int, _P, C.c_int, _P],
+    "dqn_cnn_set_optimizer": [_P, _I32, _F, _F, _F, _F, _F, _P],
+    "dqn_cnn_optimizer_step": [_P, _F, _P],
+    "dqn_cnn_train_step": [_P, _P, _P, _P, _I32, _P],
+    "dqn_cnn_update": [_P, _P, _P, _P, _P, _P, _P, _F, _I32, _P, _P],
+    "dqn_cnn_sync_target": [_P, _P],
 }
 OTHER = {"dqn_last_error": ([], C.c_char_p), "dqn_abi_version": ([], C.c_int),
          "dqn_default_config": ([C.POINTER(DqnConfig)], None)}

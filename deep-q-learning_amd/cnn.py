@@ -1,4 +1,4 @@
-"""Nature-CNN dueling Q-network, forward (BASELINE.json configs[4], PongNoFrameskip-v4 shape).
+"""Nature-CNN dueling Q-network: forward, loss gradient, Adam step (BASELINE.json configs[4], PongNoFrameskip-v4 shape).
 The reference has no CNN: this is the model a `Model`-like object would wrap for Atari, ending in the reference's dueling
 head (LunarLander/dddqn.py:29-31) and feeding the reference's TD rule (General/QLearning/q_learning_functions.py:55-60).
 Every computation goes through the C ABI (include/dqn_hip.h: dqn_cnn_*); there is no CPU fallback."""
@@ -70,3 +70,50 @@ class CnnEngine:
         out = torch.empty((B, self.num_actions), dtype=torch.float32, device=self.device)
         L.check(self.lib.dqn_cnn_q_targets(self.h, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), float(gamma), B, _ptr(out), self._s()))
         return out
+
+    # ---- training (train_step / Agent._step on a given minibatch)
+    def _t(self, v, dt):
+        return (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))).to(self.device, dt).contiguous()
+
+    def set_optimizer(self, lr=3e-4, b1=0.9, b2=0.999, eps=1e-8, weight_decay=1e-4, adamw=True):
+        """optax.adam / adamw (Test/lunar_lander.py:48); resets the moments and the step count"""
+        L.check(self.lib.dqn_cnn_set_optimizer(self.h, int(bool(adamw)), float(lr), float(b1), float(b2), float(eps), float(weight_decay), self._s()))
+
+    def get_buffer(self, which):
+        """flat f32 copy of "params" / "target" / "grad" / "mu" / "nu" """
+        out = torch.empty(self.param_count, dtype=torch.float32, device=self.device)
+        L.check(self.lib.dqn_cnn_get_buffer(self.h, {"params": L.BUF_PARAMS, "target": L.BUF_TARGET, "grad": L.BUF_GRAD, "mu": L.BUF_MU, "nu": L.BUF_NU}[which],
+                                           _ptr(out), 0, self._s()))
+        return out
+
+    def grads(self, frames, targets, isw=None):
+        """jax.grad(compute_loss) (q_learning_functions.py:23): fills the gradient buffer, returns the loss"""
+        x = self._frames(frames)
+        t = self._t(targets, torch.float32); assert t.shape == (x.shape[0], self.num_actions), t.shape
+        w = None if isw is None else self._t(isw, torch.float32)
+        loss = C.c_float(0)
+        L.check(self.lib.dqn_cnn_grads(self.h, _ptr(x), _ptr(t), _ptr(w) if w is not None else None, x.shape[0], C.byref(loss), self._s()))
+        return loss.value
+
+    def optimizer_step(self, grad_scale=1.0):
+        L.check(self.lib.dqn_cnn_optimizer_step(self.h, float(grad_scale), self._s()))
+
+    def train_step(self, frames, targets, isw=None):
+        """train_step (q_learning_functions.py:14-28)"""
+        x = self._frames(frames)
+        t = self._t(targets, torch.float32)
+        w = None if isw is None else self._t(isw, torch.float32)
+        L.check(self.lib.dqn_cnn_train_step(self.h, _ptr(x), _ptr(t), _ptr(w) if w is not None else None, x.shape[0], self._s()))
+
+    def update(self, s, a, r, s2, d, isw=None, gamma=0.99, want_loss=False):
+        """Agent._step (q_agent.py:146-169) on a given minibatch: compute_q_targets + train_step"""
+        s, s2 = self._frames(s), self._frames(s2)
+        a, r, d = self._t(a, torch.int32), self._t(r, torch.float32), self._t(d, torch.float32)
+        w = None if isw is None else self._t(isw, torch.float32)
+        loss = C.c_float(0)
+        L.check(self.lib.dqn_cnn_update(self.h, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), _ptr(w) if w is not None else None, float(gamma), s.shape[0],
+                                        C.byref(loss) if want_loss else None, self._s()))
+        return loss.value if want_loss else None
+
+    def sync_target(self):
+        L.check(self.lib.dqn_cnn_sync_target(self.h, self._s()))

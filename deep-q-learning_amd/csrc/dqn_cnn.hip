@@ -266,15 +266,472 @@ k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const flo
     }
 }
 
-// flat f32 parameters -> transposed compute-type shadow [N][K]
+// ------------------------------------------------------------------------------------ backward (loss gradient)
+// jax.grad(compute_loss) (General/QLearning/q_learning_functions.py:23, :31-39) through the CNN, hand-derived like the MLP's
+// (dqn_net.hip). Three kinds of kernels:
+//   k_cnn_head_bwd / k_cnn_head_dw   loss, dL/dQ, dueling backward, gradient at the fc pre-activations, head leaves
+//   k_cnn_bwd_data<L>                gradient at layer L's INPUT pre-activations: dZ_L . W_L^T as an implicit GEMM in gather form
+//   k_cnn_dw<L>                      dW_L = Patch_L^T . dZ_L (reduction over the output positions), cut into row slices
+// Sums run in another order than the restatement's sample-by-sample accumulation: the bar is 1e-5 of the leaf scale against
+// the f64 form (f32 mode), 2e-2 in bf16 mode.
+
+template <typename TC, int MT>
+__device__ __forceinline__ void mfma_chunk(const TC *ar, const TC *br, int hi, f32x16c &acc) {
+    static_assert(MT == 32, "the backward kernels use 32 x 32 tiles");
+    if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8c *>(ar + 16 * ks + 8 * hi),
+                                                          *reinterpret_cast<const bf16x8c *>(br + 16 * ks + 8 * hi), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(ar + 32 * hi + 4 * q), b = *reinterpret_cast<const float4 *>(br + 32 * hi + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+}
+template <typename TR> __device__ __forceinline__ TR zero_piece();
+template <> __device__ __forceinline__ bf16x8c zero_piece<bf16x8c>() { bf16x8c z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.0f; return z; }
+template <> __device__ __forceinline__ f32x8raw zero_piece<f32x8raw>() { return f32x8raw{float4{0, 0, 0, 0}, float4{0, 0, 0, 0}}; }
+
+// Backward-data geometry of layer L (dZ_L -> gradient at a_{L-1}, masked by a_{L-1} > 0 = dZ_{L-1}):
+//   L = 3 (fc)     rows b,             K = 512 (n of the fc),            N = 3136, weights as stored ([3136][512])
+//   L = 2 (conv3)  rows (b, ih, iw) of the 9 x 9 input, K = 9 taps x 64 oc, N = 64 ic: tap (kh, kw) reads dZ[b][ih-kh][iw-kw] or 0
+//   L = 1 (conv2)  stride 2: an input pixel (ih, iw) is reached by the taps kh = (ih & 1) + 2 th, kw = (iw & 1) + 2 tw only, so
+//                  the rows are grouped into the four parity classes (each with its own 32 x 256 weight matrix): rows (b, i2, j2)
+//                  of a class, K = 4 taps x 64 oc, tap (th, tw) reads dZ[b][i2-th][j2-tw] or 0
+template <int L> struct BwdGeo;
+template <> struct BwdGeo<3> { static constexpr int K = 512, N = 3136, WM = 2, WN = 2, R = 4, CLASSES = 1, ROWS = 1; };
+template <> struct BwdGeo<2> { static constexpr int K = 576, N = 64, WM = 2, WN = 2, R = 3, CLASSES = 1, ROWS = 81; };
+template <> struct BwdGeo<1> { static constexpr int K = 256, N = 32, WM = 4, WN = 1, R = 4, CLASSES = 4, ROWS = 100; };
+
+template <typename TC, int L>
+__global__ void __launch_bounds__(256)
+k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, const TC *__restrict__ act, TC *__restrict__ out) {
+    typedef BwdGeo<L> G;
+    constexpr int MT = 32, WM = G::WM, WN = G::WN, R = G::R, K = G::K;
+    constexpr int BM = MT * WM, BN = MT * WN, NCH = K / KC, NIT = NCH / R;
+    constexpr int LS = KC + (sizeof(TC) == 2 ? 8 : 4);
+    constexpr int APT = BM * 8 / 256, BPT = BN * 8 / 256, NT = G::N / BN;
+    static_assert(WM * WN == 4 && K % KC == 0 && NCH % R == 0 && G::N % BN == 0, "tile shape");
+    typedef typename RawPiece<TC>::t RP;
+    __shared__ __attribute__((aligned(16))) TC lA[2 * BM * LS];
+    __shared__ __attribute__((aligned(16))) TC lB[2 * BN * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int M = B * G::ROWS;                                   // rows per class
+    const int mtiles = (M + BM - 1) / BM, per_class = mtiles * NT;
+    const int cl = blockIdx.x / per_class;
+    int t = blockIdx.x - cl * per_class;
+    if ((per_class & 7) == 0) t = (t & 7) * (per_class >> 3) + (t >> 3);
+    const int m0 = (t / NT) * BM, n0 = (t % NT) * BN, ph = cl >> 1, pw = cl & 1;
+    const int pj = tid & 7;
+    // a row's (b, y, x): for L = 2 the input pixel, for L = 1 the pixel's half coordinates inside its parity class
+    int rb[APT], ry[APT], rx[APT];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        int mm = m0 + (tid >> 3) + 32 * u;
+        mm = mm < M ? mm : M - 1;
+        if constexpr (L == 3) { rb[u] = mm; ry[u] = 0; rx[u] = 0; }
+        else if constexpr (L == 2) { const unsigned b = (unsigned)mm / 81u, p = (unsigned)mm - b * 81u; rb[u] = b; ry[u] = p / 9u; rx[u] = p - (p / 9u) * 9u; }
+        else { const unsigned b = (unsigned)mm / 100u, p = (unsigned)mm - b * 100u; rb[u] = b; ry[u] = p / 10u; rx[u] = p - (p / 10u) * 10u; }
+    }
+    const TC *bp[BPT];
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) bp[u] = wb + ((long long)cl * G::N + n0 + (tid >> 3) + 32 * u) * K + 8 * pj;
+    RP ra[R][APT], rbw[R][BPT];
+    auto request = [&](int slot, int kc) {
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            bool ok = true; long long off;
+            if constexpr (L == 3) off = (long long)rb[u] * 512 + kc * KC;
+            else if constexpr (L == 2) {
+                const int oh = ry[u] - kc / 3, ow = rx[u] - kc % 3;
+                ok = oh >= 0 && oh < 7 && ow >= 0 && ow < 7;
+                off = ok ? ((long long)(rb[u] * 7 + oh) * 7 + ow) * 64 : 0;
+            } else {
+                const int oh = ry[u] - kc / 2, ow = rx[u] - kc % 2;
+                ok = oh >= 0 && oh < 9 && ow >= 0 && ow < 9;
+                off = ok ? ((long long)(rb[u] * 9 + oh) * 9 + ow) * 64 : 0;
+            }
+            const RP v = load_piece<TC>(dz + off + 8 * pj);      // always loaded (a tap outside the map reads a valid address, then 0)
+            ra[slot][u] = ok ? v : zero_piece<RP>();
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) rbw[slot][u] = load_piece<TC>(bp[u] + kc * KC);
+    };
+    auto commit = [&](int slot, int buf) {
+        TC *a = lA + buf * (BM * LS) + (tid >> 3) * LS, *b = lB + buf * (BN * LS) + (tid >> 3) * LS;
+#pragma unroll
+        for (int u = 0; u < APT; ++u) commit_piece<MT>(a + 32 * u * LS, pj, ra[slot][u], nullptr);
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) commit_piece<MT>(b + 32 * u * LS, pj, rbw[slot][u], nullptr);
+    };
+    f32x16c acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int hi = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int r = 0; r < R; ++r) request(r, r);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int kc = it * R + r, buf = kc & 1;
+            commit(r, buf);
+            if (it + 1 < NIT) request(r, kc + R);
+            __syncthreads();
+            mfma_chunk<TC, MT>(lA + buf * (BM * LS) + (MT * wm + c) * LS, lB + buf * (BN * LS) + (MT * wn + c) * LS, hi, acc);
+        }
+    }
+    const int n = n0 + MT * wn + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + MT * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (mm < M) {
+            long long o;
+            if constexpr (L == 3) o = (long long)mm * 3136 + n;
+            else if constexpr (L == 2) o = (long long)mm * 64 + n;
+            else {
+                const unsigned b = (unsigned)mm / 100u, p = (unsigned)mm - b * 100u, i2 = p / 10u, j2 = p - i2 * 10u;
+                o = ((long long)(b * 20 + 2 * i2 + ph) * 20 + 2 * j2 + pw) * 32 + n;
+            }
+            out[o] = (float)act[o] > 0.0f ? (TC)acc[r] : (TC)0.0f;
+        }
+    }
+}
+
+// dW geometry of layer L: workgroup = (k-tile of KT rows of dW) x (n-tile of NT columns) x (slice of the rows m); four waves as
+// WK x WN, each (KT / WK) x (NT / WN) = TK x TN MFMA tiles. The rows of a slice are walked in super-chunks of NSC chunks of MR
+// rows: inside a super-chunk the pipeline is straight-line code (compile-time ring slots), between two the queue drains.
+template <int L> struct DwGeo;
+template <> struct DwGeo<0> { static constexpr int KT = 256, NT = 32, WK = 4, WN = 1, MR = 64, R = 2, NSC = 4; };
+template <> struct DwGeo<1> { static constexpr int KT = 256, NT = 64, WK = 4, WN = 1, MR = 32, R = 2, NSC = 4; };
+template <> struct DwGeo<2> { static constexpr int KT = 192, NT = 64, WK = 2, WN = 2, MR = 32, R = 2, NSC = 4; };
+template <> struct DwGeo<3> { static constexpr int KT = 64, NT = 128, WK = 2, WN = 2, MR = 32, R = 4, NSC = 8; };
+
+// natural-order row images for the dW kernels (the reduction runs over the ROWS of both images)
+template <typename TR>
+__device__ __forceinline__ void commit_row_piece(__bf16 *dst, const TR &raw) {
+    if constexpr (__is_same(TR, bf16x8c)) *reinterpret_cast<bf16x8c *>(dst) = raw;
+    else {
+        const uint32_t w[2] = {raw.x, raw.y};
+        bf16x8c a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (__bf16)(float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+        *reinterpret_cast<bf16x8c *>(dst) = a;
+    }
+}
+template <typename TR>
+__device__ __forceinline__ void commit_row_piece(float *dst, const TR &raw, const float *lut) {
+    float v[8]; piece_f32(raw, lut, v);
+    *reinterpret_cast<float4 *>(dst) = float4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4 *>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
+}
+
+template <typename TI, typename TC, int L>
+__global__ void __launch_bounds__(256)
+k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restrict__ dz, float *__restrict__ slab, float *__restrict__ bslab) {
+    typedef CnnGeo<L> G; typedef DwGeo<L> D;
+    constexpr int KT = D::KT, NT = D::NT, WK = D::WK, WN = D::WN, MR = D::MR, R = D::R, NSC = D::NSC;
+    constexpr int K = G::KH * G::KW * G::IC, N = G::OC, ROWLEN = G::KW * G::IC, KTILES = K / KT, NTILES = N / NT;
+    constexpr int TK = KT / WK / 32, TN = NT / WN / 32;
+    constexpr int PAD = sizeof(TC) == 2 ? 8 : 4, LSA = KT + PAD, LSB = NT + PAD;
+    constexpr int APR = KT / 8, BPR = NT / 8;                         // pieces per image row
+    constexpr int APT = MR * APR / 256, BPT = MR * BPR / 256;
+    constexpr int LBUF = sizeof(TC) == 2 ? 2 : 1;
+    static_assert(WK * WN == 4 && K % KT == 0 && N % NT == 0 && (KT % ROWLEN == 0 || ROWLEN % KT == 0), "tile shape");
+    static_assert(MR * APR % 256 == 0 && MR * BPR % 256 == 0 && NSC % R == 0 && TK >= 1 && TN >= 1, "piece split");
+    typedef typename RawPiece<TI>::t RA;
+    typedef typename RawPiece<TC>::t RB;
+    __shared__ __attribute__((aligned(16))) TC lA[LBUF * MR * LSA];
+    __shared__ __attribute__((aligned(16))) TC lB[LBUF * MR * LSB];
+    __shared__ float lut[(sizeof(TI) == 1 && sizeof(TC) == 4) ? 256 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave / WN, wn = wave % WN, hi = lane >> 5, c = lane & 31;
+    if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) { lut[tid] = __fdiv_rn((float)tid, 255.0f); __syncthreads(); }
+    const int tile = blockIdx.x % (KTILES * NTILES), slice = blockIdx.x / (KTILES * NTILES);
+    const int kt0 = (tile / NTILES) * KT, n0 = (tile % NTILES) * NT;
+    const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
+    // this thread's pieces: image row and offset inside the patch row / the dZ row
+    int arow[APT], akoff[APT], brow[BPT], bcol[BPT];
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        const int q = tid + 256 * u, kp = kt0 + 8 * (q % APR), kh = kp / ROWLEN;
+        arow[u] = q / APR; akoff[u] = kh * (G::IW * G::IC) + (kp - kh * ROWLEN);
+    }
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) { const int q = tid + 256 * u; brow[u] = q / BPR; bcol[u] = 8 * (q % BPR); }
+    RA ra[R][APT]; RB rb[R][BPT];
+    auto request = [&](int slot, int mc) {                             // mc: first row of the chunk
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            int mm = mc + arow[u]; mm = mm < M ? mm : M - 1;
+            const unsigned ow = (unsigned)mm % G::OW, t2 = (unsigned)mm / G::OW, oh = t2 % G::OH, b = t2 / G::OH;
+            ra[slot][u] = load_piece<TI>(in + ((long long)(b * G::IH + oh * G::S) * G::IW + ow * G::S) * G::IC + akoff[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const int mm = mc + brow[u];
+            const RB v = load_piece<TC>(dz + (long long)(mm < M ? mm : M - 1) * N + n0 + bcol[u]);
+            rb[slot][u] = mm < m_end ? v : zero_piece<RB>();           // rows past the slice contribute nothing
+        }
+    };
+    auto commit = [&](int slot, int buf) {
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            TC *dst = lA + buf * (MR * LSA) + arow[u] * LSA + 8 * ((tid + 256 * u) % APR);
+            if constexpr (sizeof(TC) == 2) commit_row_piece(dst, ra[slot][u]); else commit_row_piece(dst, ra[slot][u], lut);
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            TC *dst = lB + buf * (MR * LSB) + brow[u] * LSB + bcol[u];
+            if constexpr (sizeof(TC) == 2) commit_row_piece(dst, rb[slot][u]); else commit_row_piece(dst, rb[slot][u], nullptr);
+        }
+    };
+    f32x16c acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float bsum = 0.0f;
+    auto multiply = [&](int buf) {
+        const TC *a = lA + buf * (MR * LSA) + (wk * TK * 32 + c), *b = lB + buf * (MR * LSB) + (wn * TN * 32 + c);
+        if (tile / NTILES == 0 && tid < NT) {                          // bias gradient: column sums of dZ (k-tile 0 only)
+            const TC *col = lB + buf * (MR * LSB) + tid;
+#pragma unroll 8
+            for (int r = 0; r < MR; ++r) bsum = bsum + (float)col[r * LSB];
+        }
+        if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+            for (int s = 0; s < MR / 16; ++s) {
+                bf16x8c fa[TK], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TK; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fa[i][e] = a[(16 * s + 8 * hi + e) * LSA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fb[j][e] = b[(16 * s + 8 * hi + e) * LSB + 32 * j];
+#pragma unroll
+                for (int i = 0; i < TK; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int s = 0; s < MR / 2; ++s) {
+                float fa[TK], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TK; ++i) fa[i] = a[(2 * s + hi) * LSA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = b[(2 * s + hi) * LSB + 32 * j];
+#pragma unroll
+                for (int i = 0; i < TK; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    for (int ms = m_begin; ms < m_end; ms += NSC * MR) {               // one super-chunk: straight-line pipeline
+#pragma unroll
+        for (int r = 0; r < R; ++r) request(r, ms + r * MR);
+#pragma unroll
+        for (int j = 0; j < NSC; ++j) {
+            const int buf = LBUF == 2 ? (j & 1) : 0;
+            commit(j % R, buf);
+            if (j + R < NSC) request(j % R, ms + (j + R) * MR);
+            __syncthreads();
+            multiply(buf);
+            if constexpr (LBUF == 1) __syncthreads();
+        }
+        if constexpr (LBUF == 2 && (NSC & 1)) __syncthreads();
+    }
+    float *o = slab + (long long)slice * K * N;
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt0 + (wk * TK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, n = n0 + (wn * TN + j) * 32 + c;
+                o[(long long)k * N + n] = acc[i][j][r];
+            }
+    if (tile / NTILES == 0 && tid < NT) bslab[(long long)slice * N + n0 + tid] = bsum;
+}
+
+// Loss, dL/dQ and the dueling backward (as k_bwd_rows in dqn_net.hip: g = w clip(q - target, -1, 1) / B, dv = sum g,
+// dadv = g - mean g), then the gradient at the fc pre-activations: dz4[i][k] = a3 > 0 ? wv[k] dv + sum_j wa[k][j] dadv_j : 0.
+// 16 rows per workgroup; gd[i][0] = dv, gd[i][1 + j] = dadv_j; one loss partial per workgroup.
 template <typename TC>
 __global__ void __launch_bounds__(256)
-k_cnn_pack(const float *__restrict__ w, int K, int N, float div, TC *__restrict__ wt) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)K * N) return;
-    const int n = (int)(t / K), k = (int)(t - (long long)n * K);
-    const float v = w[(long long)k * N + n];
-    wt[t] = (TC)(div != 1.0f ? __fdiv_rn(v, div) : v);
+k_cnn_head_bwd(const float *__restrict__ q, const float *__restrict__ targets, const float *__restrict__ isw, const TC *__restrict__ feat,
+               const float *__restrict__ wht, int A, int B, float *__restrict__ gd, TC *__restrict__ dz4, float *__restrict__ loss_part) {
+    __shared__ float lg[16 * 16], lrow[16];
+    const int tid = threadIdx.x, r0 = blockIdx.x * 16;
+    if (tid < 16) {
+        const int i = r0 + tid;
+        float row = 0.0f, gsum = 0.0f, g[16];
+        if (i < B) {
+            const float w = isw ? isw[i] : 1.0f, invB = __fdiv_rn(1.0f, (float)B);
+            for (int j = 0; j < A; ++j) {
+                const float e = q[(long long)i * A + j] - targets[(long long)i * A + j];
+                row = row + huber(e);
+                const float cpd = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+                g[j] = (w * cpd) * invB;
+                gsum = gsum + g[j];
+            }
+            if (isw) row = w * row;
+            const float gmean = __fdiv_rn(gsum, (float)A);
+            lg[16 * tid] = gsum;
+            for (int j = 0; j < A; ++j) lg[16 * tid + 1 + j] = g[j] - gmean;
+            for (int j = A + 1; j < 16; ++j) lg[16 * tid + j] = 0.0f;
+            for (int j = 0; j < 16; ++j) gd[(long long)i * 16 + j] = lg[16 * tid + j];
+        } else for (int j = 0; j < 16; ++j) lg[16 * tid + j] = 0.0f;
+        lrow[tid] = row;
+    }
+    __syncthreads();
+    if (tid == 0) { float s = 0.0f; for (int r = 0; r < 16; ++r) s = s + lrow[r]; loss_part[blockIdx.x] = s; }
+    // thread: 2 columns k of all 16 rows
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = tid + 256 * kk;
+        float w[16];
+        for (int j = 0; j <= A; ++j) w[j] = wht[j * CNN_F + k];
+        for (int r = 0; r < 16; ++r) {
+            const int i = r0 + r;
+            if (i >= B) break;
+            float t = w[0] * lg[16 * r];
+            for (int j = 1; j <= A; ++j) t = fmaf(w[j], lg[16 * r + j], t);
+            const long long o = (long long)i * CNN_F + k;
+            dz4[o] = (float)feat[o] > 0.0f ? (TC)t : (TC)0.0f;
+        }
+    }
+}
+
+// head leaves: grad wv[k] = sum_i a3[i][k] dv_i, wa[k][j] = sum_i a3[i][k] dadv_ij (i ascending, one chain per element);
+// bv, ba = column sums of gd. grid: 512 * 16 / 256 blocks (+ 1 for the biases).
+template <typename TC>
+__global__ void __launch_bounds__(256)
+k_cnn_head_dw(const TC *__restrict__ feat, const float *__restrict__ gd, int A, int B, float *__restrict__ g_wv, float *__restrict__ g_bv,
+              float *__restrict__ g_wa, float *__restrict__ g_ba) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == CNN_F * 16 / 256) {
+        if (threadIdx.x <= A) {
+            float s = 0.0f;
+            for (int i = 0; i < B; ++i) s = s + gd[(long long)i * 16 + threadIdx.x];
+            if (threadIdx.x == 0) g_bv[0] = s; else g_ba[threadIdx.x - 1] = s;
+        }
+        return;
+    }
+    const int j = t / CNN_F, k = t - j * CNN_F;
+    if (j > A) return;
+    float acc = 0.0f;
+    int i = 0;
+    for (; i + 8 <= B; i += 8) {
+        float x[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = (float)feat[(long long)(i + u) * CNN_F + k]; d[u] = gd[(long long)(i + u) * 16 + j]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(x[u], d[u], acc);
+    }
+    for (; i < B; ++i) acc = fmaf((float)feat[(long long)i * CNN_F + k], gd[(long long)i * 16 + j], acc);
+    if (j == 0) g_wv[k] = acc; else g_wa[(long long)k * A + (j - 1)] = acc;
+}
+
+// grad leaf = sum over the slices of its slab, in slice order (deterministic); loss = sum of the head partials / B
+struct CnnSeg { const float *slab; long long n, dst; int S; float div; };
+struct CnnSegs { CnnSeg s[8]; };
+__global__ void __launch_bounds__(256)
+k_cnn_reduce(CnnSegs segs, long long total, float *__restrict__ grad, const float *__restrict__ loss_part, int loss_parts, int B, float *__restrict__ loss) {
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0 && loss) { float s = 0.0f; for (int i = 0; i < loss_parts; ++i) s = s + loss_part[i]; *loss = __fdiv_rn(s, (float)B); }
+    if (t >= total) return;
+    int g = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) if (t >= segs.s[g].n) { t -= segs.s[g].n; ++g; }
+    const CnnSeg sg = segs.s[g];
+    const float *p = sg.slab + t;
+    float acc = 0.0f;
+    int s = 0;
+    for (; s + 8 <= sg.S; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * sg.n];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+    }
+    for (; s < sg.S; ++s) acc = acc + p[(long long)s * sg.n];
+    grad[sg.dst + t] = sg.div != 1.0f ? __fdiv_rn(acc, sg.div) : acc;
+}
+
+// every compute-type shadow of flat parameter element i (value v): forward [N][K] (conv1's scaled by 1/255 in bf16 mode),
+// backward-data (BwdGeo), output-major heads
+struct CnnOffs { long long o_w[4], o_b[4], o_wv, o_bv, o_wa, o_ba, P; int A; };
+template <typename TC>
+struct CnnShadows { TC *wt[4]; TC *wb[4]; float *wh, *bh; };
+template <typename TC>
+__device__ __forceinline__ void scatter_shadows(const CnnOffs &o, const CnnShadows<TC> &sh, long long i, float v) {
+    if (i >= o.o_wv) {
+        if (i < o.o_bv) sh.wh[i - o.o_wv] = v;
+        else if (i < o.o_wa) sh.bh[0] = v;
+        else if (i < o.o_ba) { const long long e = i - o.o_wa; const int k = (int)(e / o.A), j = (int)(e - (long long)k * o.A); sh.wh[(1 + j) * CNN_F + k] = v; }
+        else sh.bh[1 + (i - o.o_ba)] = v;
+        return;
+    }
+    int l = 0;
+#pragma unroll
+    for (int u = 1; u < 4; ++u) if (i >= o.o_w[u]) l = u;
+    if (i >= o.o_b[l]) return;                                         // conv / fc biases are read from the flat vector
+    const int N = l == 0 ? 32 : (l == 3 ? 512 : 64), K = l == 0 ? 256 : (l == 1 ? 512 : (l == 2 ? 576 : 3136));
+    const long long e = i - o.o_w[l];
+    const int k = (int)(e / N), n = (int)(e - (long long)k * N);
+    const float vf = (l == 0 && sizeof(TC) == 2) ? __fdiv_rn(v, 255.0f) : v;
+    sh.wt[l][(long long)n * K + k] = (TC)vf;
+    if (l == 3) sh.wb[3][e] = (TC)v;
+    else if (l == 2) { const int tap = k >> 6, ic = k & 63; sh.wb[2][(long long)ic * 576 + tap * 64 + n] = (TC)v; }
+    else if (l == 1) {
+        const int tap = k >> 5, ic = k & 31, kh = tap >> 2, kw = tap & 3, cl = (kh & 1) * 2 + (kw & 1), tt = (kh >> 1) * 2 + (kw >> 1);
+        sh.wb[1][((long long)cl * 32 + ic) * 256 + tt * 64 + n] = (TC)v;
+    }
+}
+template <typename TC>
+__global__ void __launch_bounds__(256)
+k_cnn_scatter(CnnOffs o, CnnShadows<TC> sh, const float *__restrict__ P) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < o.P) scatter_shadows<TC>(o, sh, i, P[i]);
+}
+
+// optax adam / adamw element (adam_elem, dqn_net_common.h) + shadow refresh; the step counters live in CnnOptState and are
+// advanced by k_cnn_opt_bump behind this kernel
+struct CnnOptState { double b1pow, b2pow; int count; float lr; };
+template <typename TC>
+__global__ void __launch_bounds__(256)
+k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, float *P, const float *__restrict__ grad, float *mu, float *nu,
+           int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= o.P) return;
+    const double b1p = st->b1pow * (double)b1, b2p = st->b2pow * (double)b2;
+    const AdamCoef c{(float)(1.0 - b1p), (float)(1.0 - b2p), 1.0f - b1, 1.0f - b2, -st->lr};
+    const float gi = grad[i] * grad_scale;
+    const float mm = (b1 * mu[i]) + (c.omb1 * gi);
+    const float vv = (b2 * nu[i]) + (c.omb2 * (gi * gi));
+    mu[i] = mm; nu[i] = vv;
+    const float mhat = __fdiv_rn(mm, c.c1), vhat = __fdiv_rn(vv, c.c2);
+    float u = __fdiv_rn(mhat, sqrtf(vhat) + eps);
+    float p = P[i];
+    if (adamw) u = u + (wd * p);
+    p = p + (c.neglr * u);
+    P[i] = p;
+    scatter_shadows<TC>(o, sh, i, p);
+}
+__global__ void k_cnn_opt_bump(CnnOptState *st, float b1, float b2) {
+    st->b1pow *= (double)b1; st->b2pow *= (double)b2; st->count += 1;
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -283,21 +740,51 @@ k_cnn_pack(const float *__restrict__ w, int K, int N, float div, TC *__restrict_
 
 struct CnnLayer { int K, N; long long o_w, o_b; };     // offsets into the flat parameter vector
 struct dqn_cnn_handle {
-    int A = 0, max_batch = 0; bool bf16 = false;
+    int A = 0, max_batch = 0, num_cus = 256; bool bf16 = false;
     CnnLayer L[4]; long long o_wv = 0, o_bv = 0, o_wa = 0, o_ba = 0, P = 0;
     void *arena = nullptr;
     float *params[2] = {nullptr, nullptr};             // online, target (flat f32, HWIO leaf order)
-    void *wt[2][4] = {{nullptr}};                      // transposed shadows of the four GEMM layers
+    void *wt[2][4] = {{nullptr}};                      // forward shadows [N][K] of the four GEMM layers
+    void *wb[2][4] = {{nullptr}};                      // backward-data shadows (BwdGeo; [1..3])
     float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads, output-major [16][512] (0 = val, 1.. = adv), biases [1 + A]
-    void *act[4] = {nullptr};                          // layer outputs
+    void *act[4] = {nullptr};                          // layer outputs (kept for the backward)
+    void *dz[4] = {nullptr};                           // gradients at the layers' pre-activations (same shapes)
     float *q[3] = {nullptr, nullptr, nullptr};         // Q of the three passes of compute_q_targets
     float *scratch = nullptr;
+    float *grad = nullptr, *mu = nullptr, *nu = nullptr, *gd = nullptr, *loss_part = nullptr, *loss = nullptr, *targets = nullptr;
+    float *slab[4] = {nullptr}, *bslab[4] = {nullptr}; int smax[4] = {1, 1, 1, 1};
+    CnnOptState *opt = nullptr;
+    int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
 };
 
 struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
 template <int L> static LayerShape shape_of() { typedef CnnGeo<L> G; return LayerShape{G::KH * G::KW * G::IC, G::OC, G::OH * G::OW}; }
 static LayerShape cnn_shape(int layer) {
     switch (layer) { case 0: return shape_of<0>(); case 1: return shape_of<1>(); case 2: return shape_of<2>(); default: return shape_of<3>(); }
+}
+struct DwShape { int tiles, unit; };                    // (k-tiles x n-tiles) of DwGeo<l>; rows of one super-chunk
+template <int L> static DwShape dw_shape_of() { typedef CnnGeo<L> G; typedef DwGeo<L> D; return DwShape{(G::KH * G::KW * G::IC / D::KT) * (G::OC / D::NT), D::NSC * D::MR}; }
+static DwShape dw_shape(int layer) {
+    switch (layer) { case 0: return dw_shape_of<0>(); case 1: return dw_shape_of<1>(); case 2: return dw_shape_of<2>(); default: return dw_shape_of<3>(); }
+}
+// rows of layer l's dW are cut into at most smax[l] slices of whole super-chunks
+static int dw_rows_per_slice(const dqn_cnn_handle *h, int l, long long M) {
+    const DwShape d = dw_shape(l);
+    const long long per = (M + (long long)h->smax[l] * d.unit - 1) / ((long long)h->smax[l] * d.unit);
+    return (int)(per < 1 ? 1 : per) * d.unit;
+}
+
+static CnnOffs cnn_offs(const dqn_cnn_handle *h) {
+    CnnOffs o{};
+    for (int l = 0; l < 4; ++l) { o.o_w[l] = h->L[l].o_w; o.o_b[l] = h->L[l].o_b; }
+    o.o_wv = h->o_wv; o.o_bv = h->o_bv; o.o_wa = h->o_wa; o.o_ba = h->o_ba; o.P = h->P; o.A = h->A;
+    return o;
+}
+template <typename TC> static CnnShadows<TC> cnn_shadows(const dqn_cnn_handle *h, int which) {
+    CnnShadows<TC> s{};
+    for (int l = 0; l < 4; ++l) { s.wt[l] = (TC *)h->wt[which][l]; s.wb[l] = (TC *)h->wb[which][l]; }
+    s.wh = h->wh[which]; s.bh = h->bh[which];
+    return s;
 }
 
 extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out) {
@@ -306,31 +793,46 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     dqn_cnn_handle *h = new (std::nothrow) dqn_cnn_handle();
     if (!h) return dqn_set_error(DQN_ERR_NOMEM, "host allocation failed");
     h->A = num_actions; h->max_batch = max_batch; h->bf16 = precision == DQN_PREC_BF16;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) h->num_cus = cus;
     long long p = 0;
     for (int l = 0; l < 4; ++l) {
         const LayerShape g = cnn_shape(l);
         h->L[l] = CnnLayer{g.K, g.OC, p, p + (long long)g.K * g.OC};
         p += (long long)g.K * g.OC + g.OC;
+        const int t = dw_shape(l).tiles;
+        h->smax[l] = t >= h->num_cus ? 1 : (t > h->num_cus / 2 ? 2 : h->num_cus / t);
     }
     h->o_wv = p; p += 512; h->o_bv = p; p += 1; h->o_wa = p; p += 512ll * h->A; h->o_ba = p; p += h->A; h->P = p;
     const size_t esz = h->bf16 ? 2 : 4;
-    size_t total = 0;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-    size_t sz_params = al(h->P * 4), sz_wt[4], sz_act[4], sz_wh = al(16 * CNN_F * 4), sz_bh = al((h->A + 1) * 4), sz_q = al((size_t)max_batch * h->A * 4);
-    for (int l = 0; l < 4; ++l) { sz_wt[l] = al((size_t)h->L[l].K * h->L[l].N * esz); sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz); }
-    total = 2 * sz_params + 2 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + sz_act[0] + sz_act[1] + sz_act[2] + sz_act[3] + 3 * sz_q + al((size_t)max_batch * 4);
+    const size_t sz_params = al(h->P * 4), sz_wh = al(16 * CNN_F * 4), sz_bh = al(16 * 4), sz_q = al((size_t)max_batch * 16 * 4);
+    size_t sz_wt[4], sz_act[4], sz_slab[4], sz_bslab[4];
+    for (int l = 0; l < 4; ++l) {
+        sz_wt[l] = al((size_t)h->L[l].K * h->L[l].N * esz);
+        sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz);
+        sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
+    }
+    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 3 * al((size_t)max_batch * 4) + 1024;
+    for (int l = 0; l < 4; ++l) total += 2 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
     char *c = (char *)h->arena;
+    auto take = [&](size_t n) { char *r = c; c += n; return r; };
     for (int w = 0; w < 2; ++w) {
-        h->params[w] = (float *)c; c += sz_params;
-        for (int l = 0; l < 4; ++l) { h->wt[w][l] = c; c += sz_wt[l]; }
-        h->wh[w] = (float *)c; c += sz_wh; h->bh[w] = (float *)c; c += sz_bh;
+        h->params[w] = (float *)take(sz_params);
+        for (int l = 0; l < 4; ++l) { h->wt[w][l] = take(sz_wt[l]); h->wb[w][l] = take(sz_wt[l]); }
+        h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh);
     }
-    for (int l = 0; l < 4; ++l) { h->act[l] = c; c += sz_act[l]; }
-    for (int i = 0; i < 3; ++i) { h->q[i] = (float *)c; c += sz_q; }
-    h->scratch = (float *)c;
+    h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
+    for (int l = 0; l < 4; ++l) { h->act[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
+    for (int i = 0; i < 3; ++i) h->q[i] = (float *)take(sz_q);
+    h->gd = (float *)take(sz_q); h->targets = (float *)take(sz_q);
+    h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
+    h->loss = (float *)take(256); h->opt = (CnnOptState *)take(256);
     (void)hipMemset(h->arena, 0, total);
+    const CnnOptState st0{1.0, 1.0, 0, 3e-4f};
+    (void)hipMemcpy(h->opt, &st0, sizeof(st0), hipMemcpyHostToDevice);
     *out = h;
     return DQN_OK;
 }
@@ -349,12 +851,10 @@ extern "C" int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n) {
     return DQN_OK;
 }
 
-__global__ void __launch_bounds__(256)
-k_cnn_pack_head(const float *__restrict__ P, long long o_wv, long long o_bv, long long o_wa, long long o_ba, int A, float *wh, float *bh) {
-    const int t = blockIdx.x * 256 + threadIdx.x;                  // grid covers 16 * 512
-    const int j = t / CNN_F, k = t - j * CNN_F;
-    wh[t] = j == 0 ? P[o_wv + k] : (j <= A ? P[o_wa + (long long)k * A + (j - 1)] : 0.0f);
-    if (t <= A) bh[t] = t == 0 ? P[o_bv] : P[o_ba + t - 1];
+static void cnn_refresh_shadows(dqn_cnn_handle *h, int which, hipStream_t s) {
+    const unsigned blocks = (unsigned)((h->P + 255) / 256);
+    if (h->bf16) hipLaunchKernelGGL((k_cnn_scatter<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, which), h->params[which]);
+    else hipLaunchKernelGGL((k_cnn_scatter<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, which), h->params[which]);
 }
 
 // which: DQN_NET_ONLINE / DQN_NET_TARGET. Flat f32: conv1 w[8,8,4,32] b[32] conv2 w[4,4,32,64] b[64] conv3 w[3,3,64,64] b[64]
@@ -363,15 +863,29 @@ extern "C" int dqn_cnn_set_params(dqn_cnn_handle *h, int which, const float *src
     CNN_REQ(h && src && (which == DQN_NET_ONLINE || which == DQN_NET_TARGET), "bad argument");
     hipStream_t s = (hipStream_t)stream;
     CNN_TRY(hipMemcpyAsync(h->params[which], src, h->P * 4, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
-    for (int l = 0; l < 4; ++l) {
-        const long long n = (long long)h->L[l].K * h->L[l].N;
-        const int blocks = (int)((n + 255) / 256);
-        if (h->bf16) hipLaunchKernelGGL((k_cnn_pack<__bf16>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, l == 0 ? 255.0f : 1.0f, (__bf16 *)h->wt[which][l]);
-        else hipLaunchKernelGGL((k_cnn_pack<float>), dim3(blocks), dim3(256), 0, s, h->params[which] + h->L[l].o_w, h->L[l].K, h->L[l].N, 1.0f, (float *)h->wt[which][l]);
-    }
-    hipLaunchKernelGGL(k_cnn_pack_head, dim3(16 * CNN_F / 256), dim3(256), 0, s, h->params[which], h->o_wv, h->o_bv, h->o_wa, h->o_ba, h->A, h->wh[which], h->bh[which]);
+    cnn_refresh_shadows(h, which, s);
     CNN_TRY(hipGetLastError());
     if (src_is_host) CNN_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+/* which_buf: DQN_BUF_PARAMS / _TARGET / _GRAD / _MU / _NU (P floats each) */
+extern "C" int dqn_cnn_get_buffer(dqn_cnn_handle *h, int which_buf, float *dst, int dst_is_host, void *stream) {
+    CNN_REQ(h && dst, "null argument");
+    const float *src = which_buf == DQN_BUF_PARAMS ? h->params[0] : which_buf == DQN_BUF_TARGET ? h->params[1] : which_buf == DQN_BUF_GRAD ? h->grad
+                     : which_buf == DQN_BUF_MU ? h->mu : which_buf == DQN_BUF_NU ? h->nu : nullptr;
+    CNN_REQ(src, "unknown buffer");
+    CNN_TRY(hipMemcpyAsync(dst, src, h->P * 4, dst_is_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (dst_is_host) CNN_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return DQN_OK;
+}
+
+/* Agent._update_target_model (General/QLearning/q_agent.py:143-144) */
+extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
+    CNN_REQ(h, "null handle");
+    CNN_TRY(hipMemcpyAsync(h->params[1], h->params[0], h->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    cnn_refresh_shadows(h, 1, (hipStream_t)stream);
+    CNN_TRY(hipGetLastError());
     return DQN_OK;
 }
 
@@ -403,16 +917,113 @@ extern "C" int dqn_cnn_forward(dqn_cnn_handle *h, int which, const uint8_t *fram
     return DQN_OK;
 }
 
-/* compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model: three forwards + the TD rule (k_td). */
+/* compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model: three forwards + the TD rule (k_td).
+ * targets: [B][A] (the predictions with the taken action's entry replaced, :61-63). The online pass over s runs last, so its
+ * activations are the ones left in the handle (dqn_cnn_update continues with the backward from them). */
 extern "C" int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
                                  const float *d, float gamma, int32_t B, float *targets, void *stream) {
     CNN_REQ(h && s && a && r && s2 && d && targets, "null argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
-    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s, B, h->q[0], stream); if (rc) return rc;      // :52
-    rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s2, B, h->q[1], stream); if (rc) return rc;          // :53
-    rc = dqn_cnn_forward(h, DQN_NET_TARGET, s2, B, h->q[2], stream); if (rc) return rc;          // :54
+    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s2, B, h->q[1], stream); if (rc) return rc;          // :53
+    rc = dqn_cnn_forward(h, DQN_NET_TARGET, s2, B, h->q[2], stream); if (rc) return rc;              // :54
+    rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s, B, h->q[0], stream); if (rc) return rc;               // :52
     launch_td(st, h->q[0], h->q[1], h->q[2], a, r, d, nullptr, gamma, B, h->A, targets, nullptr, nullptr, nullptr, h->scratch);
     CNN_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+template <typename TI, typename TC, int L>
+static void launch_dw(dqn_cnn_handle *h, hipStream_t s, int B, const TI *in, const TC *dz, CnnSegs &segs, int &nseg, float div) {
+    typedef CnnGeo<L> G;
+    const int M = B * G::OH * G::OW, rows = dw_rows_per_slice(h, L, M), S = (M + rows - 1) / rows, tiles = dw_shape(L).tiles;
+    DQN_LAUNCH((k_cnn_dw<TI, TC, L>), dim3((unsigned)(tiles * S)), dim3(256), 0, s, M, rows, in, dz, h->slab[L], h->bslab[L]);
+    segs.s[nseg++] = CnnSeg{h->slab[L], (long long)h->L[L].K * h->L[L].N, h->L[L].o_w, S, div};
+    segs.s[nseg++] = CnnSeg{h->bslab[L], (long long)h->L[L].N, h->L[L].o_b, S, 1.0f};
+}
+template <typename TC, int L>
+static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
+    typedef BwdGeo<L> G;
+    const int BM = 32 * G::WM, BN = 32 * G::WN, M = B * G::ROWS;
+    DQN_LAUNCH((k_cnn_bwd_data<TC, L>), dim3((unsigned)(G::CLASSES * ((M + BM - 1) / BM) * (G::N / BN))), dim3(256), 0, s, B, (const TC *)h->dz[L],
+               (const TC *)h->wb[0][L], (const TC *)h->act[L - 1], (TC *)h->dz[L - 1]);
+}
+
+// backward from the activations the last online forward left in the handle and its predictions q
+template <typename TC>
+static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s) {
+    const int blocks = (B + 15) / 16;
+    hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, h->gd, (TC *)h->dz[3], h->loss_part);
+    hipLaunchKernelGGL((k_cnn_head_dw<TC>), dim3(CNN_F * 16 / 256 + 1), dim3(256), 0, s, (const TC *)h->act[3], h->gd, h->A, B, h->grad + h->o_wv, h->grad + h->o_bv,
+                       h->grad + h->o_wa, h->grad + h->o_ba);
+    CnnSegs segs{}; int nseg = 0;
+    launch_bwd_data<TC, 3>(h, s, B);
+    launch_dw<TC, TC, 3>(h, s, B, (const TC *)h->act[2], (const TC *)h->dz[3], segs, nseg, 1.0f);
+    launch_bwd_data<TC, 2>(h, s, B);
+    launch_dw<TC, TC, 2>(h, s, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
+    launch_bwd_data<TC, 1>(h, s, B);
+    launch_dw<TC, TC, 1>(h, s, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
+    launch_dw<uint8_t, TC, 0>(h, s, B, frames, (const TC *)h->dz[0], segs, nseg, sizeof(TC) == 2 ? 255.0f : 1.0f);   // bf16 mode multiplies integer pixels
+    long long total = 0;
+    for (int i = 0; i < nseg; ++i) total += segs.s[i].n;
+    hipLaunchKernelGGL(k_cnn_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs, total, h->grad, h->loss_part, blocks, B, h->loss);
+}
+
+/* gradient of compute_loss (q_learning_functions.py:31-39: mean_i w_i sum_a huber(model(s_i)[a] - targets[i][a])) w.r.t. every
+ * leaf, into the handle's gradient buffer (dqn_cnn_get_buffer(DQN_BUF_GRAD)); loss_host (optional) receives the loss. */
+extern "C" int dqn_cnn_grads(dqn_cnn_handle *h, const uint8_t *frames, const float *targets, const float *isw, int32_t B, float *loss_host, void *stream) {
+    CNN_REQ(h && frames && targets, "null argument");
+    CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, frames, B, h->q[0], stream); if (rc) return rc;
+    if (h->bf16) cnn_backward_t<__bf16>(h, frames, h->q[0], targets, isw, B, s); else cnn_backward_t<float>(h, frames, h->q[0], targets, isw, B, s);
+    CNN_TRY(hipGetLastError());
+    if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, s)); CNN_TRY(hipStreamSynchronize(s)); }
+    return DQN_OK;
+}
+
+/* optimizer = optax.adam / adamw(lr, b1, b2, eps, weight_decay) (Test/lunar_lander.py:48); resets moments and step count */
+extern "C" int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr, float b1, float b2, float eps, float weight_decay, void *stream) {
+    CNN_REQ(h && lr >= 0.0f && b1 >= 0.0f && b1 < 1.0f && b2 >= 0.0f && b2 < 1.0f && eps >= 0.0f, "bad optimizer argument");
+    hipStream_t s = (hipStream_t)stream;
+    h->adamw = adamw != 0; h->b1 = b1; h->b2 = b2; h->eps = eps; h->wd = weight_decay;
+    const CnnOptState st0{1.0, 1.0, 0, lr};
+    CNN_TRY(hipMemcpyAsync(h->opt, &st0, sizeof(st0), hipMemcpyHostToDevice, s));
+    CNN_TRY(hipMemsetAsync(h->mu, 0, h->P * 4, s)); CNN_TRY(hipMemsetAsync(h->nu, 0, h->P * 4, s));
+    CNN_TRY(hipStreamSynchronize(s));
+    return DQN_OK;
+}
+
+/* optimizer.update + optax.apply_updates (q_learning_functions.py:24-25) on the gradient buffer; refreshes the shadows */
+extern "C" int dqn_cnn_optimizer_step(dqn_cnn_handle *h, float grad_scale, void *stream) {
+    CNN_REQ(h, "null handle");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((h->P + 255) / 256);
+    if (h->bf16) hipLaunchKernelGGL((k_cnn_adam<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
+                                    h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+    else hipLaunchKernelGGL((k_cnn_adam<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
+                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+    hipLaunchKernelGGL(k_cnn_opt_bump, dim3(1), dim3(1), 0, s, h->opt, h->b1, h->b2);
+    CNN_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+/* train_step (q_learning_functions.py:14-28) */
+extern "C" int dqn_cnn_train_step(dqn_cnn_handle *h, const uint8_t *frames, const float *targets, const float *isw, int32_t B, void *stream) {
+    int rc = dqn_cnn_grads(h, frames, targets, isw, B, nullptr, stream); if (rc) return rc;
+    return dqn_cnn_optimizer_step(h, 1.0f, stream);
+}
+
+/* Agent._step (q_agent.py:146-169) on a given minibatch: compute_q_targets (three forwards), then train_step's backward from
+ * the activations of the online pass over s (the fourth forward of the reference's two separate jits is the same numbers),
+ * Adam / AdamW. loss_host optional. */
+extern "C" int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
+                              const float *isw, float gamma, int32_t B, float *loss_host, void *stream) {
+    int rc = dqn_cnn_q_targets(h, s, a, r, s2, d, gamma, B, h->targets, stream); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st);
+    CNN_TRY(hipGetLastError());
+    rc = dqn_cnn_optimizer_step(h, 1.0f, stream); if (rc) return rc;
+    if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
     return DQN_OK;
 }

@@ -237,13 +237,13 @@ int dqn_comm_count_host(dqn_handle *h, int32_t *ranks);   /* ncclCommCount of th
  * results since then are not to be trusted. */
 int dqn_device_errors_host(dqn_handle *h, int64_t *count);
 
-/* ---- Nature-CNN dueling Q-network, forward (BASELINE configs[4], PongNoFrameskip-v4 shape). Not in
+/* ---- Nature-CNN dueling Q-network (BASELINE configs[4], PongNoFrameskip-v4 shape). Not in
  * the reference: the trunk (conv 32x8x8/4, 64x4x4/2, 64x3x3/1, fc 512, ReLU) ends in the reference's dueling head
  * (LunarLander/dddqn.py:29-31) and feeds the reference's TD rule (q_learning_functions.py:55-60). Frames: u8
  * [B][84][84][4] (NHWC, four stacked frames), scaled by 1/255 in the first layer. Parameters, flat f32:
  * conv1 w[8,8,4,32] b[32]  conv2 w[4,4,32,64] b[64]  conv3 w[3,3,64,64] b[64]  fc w[3136,512] b[512] (rows in [7][7][64]
  * order)  val w[512,1] b[1]  adv w[512,A] b[A].  precision: DQN_PREC_F32 = exact f32 MFMA (k-ascending fmaf chains),
- * DQN_PREC_BF16 = bf16 MFMA operands, f32 accumulate. Forward only in this round (no CNN backward yet). */
+ * DQN_PREC_BF16 = bf16 MFMA operands, f32 accumulate. */
 typedef struct dqn_cnn_handle dqn_cnn_handle;
 int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out);
 int dqn_cnn_destroy(dqn_cnn_handle *h);
@@ -253,6 +253,25 @@ int dqn_cnn_forward(dqn_cnn_handle *h, int which_net, const uint8_t *frames, int
 /* compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model: d is f32 (preprocessing :84) */
 int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
                       const float *d, float gamma, int32_t B, float *targets, void *stream);
+/* jax.grad(compute_loss) (q_learning_functions.py:23, :31-39: mean_i w_i sum_a huber(model(s_i)[a] - targets[i][a])) w.r.t.
+ * every leaf, into the handle's gradient buffer; targets [B][A], isw [B] or NULL, loss_host optional (synchronises). */
+int dqn_cnn_grads(dqn_cnn_handle *h, const uint8_t *frames, const float *targets, const float *isw, int32_t B,
+                  float *loss_host, void *stream);
+/* which_buf: DQN_BUF_PARAMS / _TARGET / _GRAD / _MU / _NU (dqn_cnn_param_count floats each) */
+int dqn_cnn_get_buffer(dqn_cnn_handle *h, int which_buf, float *dst, int dst_is_host, void *stream);
+/* optax.adam / adamw (Test/lunar_lander.py:48); resets moments and step count */
+int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr, float b1, float b2, float eps, float weight_decay,
+                          void *stream);
+/* optimizer.update + optax.apply_updates (q_learning_functions.py:24-25) on the gradient buffer (x grad_scale) */
+int dqn_cnn_optimizer_step(dqn_cnn_handle *h, float grad_scale, void *stream);
+/* train_step (q_learning_functions.py:14-28) = dqn_cnn_grads + dqn_cnn_optimizer_step */
+int dqn_cnn_train_step(dqn_cnn_handle *h, const uint8_t *frames, const float *targets, const float *isw, int32_t B,
+                       void *stream);
+/* Agent._step (q_agent.py:146-169) on a given minibatch: compute_q_targets + train_step sharing the online pass over s */
+int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
+                   const float *isw, float gamma, int32_t B, float *loss_host, void *stream);
+/* Agent._update_target_model (q_agent.py:143-144) */
+int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream);
 
 #ifdef __cplusplus
 }

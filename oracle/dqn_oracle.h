@@ -148,6 +148,11 @@ void  orc_learner_set_nstep(orc_learner *l, int32_t n_step, int32_t n_envs);
  * val w[512,1] b[1] adv w[512,A] b[A]; frames u8 [B][84][84][4] */
 int64_t orc_cnn_param_count(int32_t A);
 void  orc_cnn_forward(const float *P, const uint8_t *frames, int32_t B, int32_t A, float *q, float *feat);
+/* gradient of mean_i w_i sum_a huber(q(s_i)[a] - targets[i][a]) (q_learning_functions.py:31-39) w.r.t. every CNN leaf */
+void  orc_cnn_grads(const float *P, const uint8_t *frames, const float *targets, const float *isw, int32_t B, int32_t A,
+                    float *grad, float *loss_out);
+void  orc_cnn_grads_f64(const float *P, const uint8_t *frames, const float *targets, const float *isw, int32_t B, int32_t A,
+                        double *grad, double *loss_out);
 
 /* all-core (OpenMP) forms of the two drivers above (dqn_oracle_omp.c; one-step returns): bit-identical results, rows and
  * weight-gradient elements spread over threads. bench.py's cpu_baseline times them beside the scalar ones. */

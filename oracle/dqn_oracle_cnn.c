@@ -70,3 +70,28 @@ void orc_cnn_forward(const float *P, const uint8_t *frames, int32_t B, int32_t A
     }
     free(x); free(a0); free(a1); free(a2); free(a3);
 }
+
+/* ---- loss gradient (f32 restatement and f64 tolerance reference): see dqn_oracle_cnn_grad.inc ---- */
+#define REAL float
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#define NAME(x) x##_f32
+#include "dqn_oracle_cnn_grad.inc"
+#undef REAL
+#undef FMA
+#undef NAME
+#define REAL double
+#define FMA(a, b, c) ((a) * (b) + (c))
+#define NAME(x) x##_f64
+#include "dqn_oracle_cnn_grad.inc"
+#undef REAL
+#undef FMA
+#undef NAME
+
+void orc_cnn_grads(const float *P, const uint8_t *frames, const float *targets, const float *isw, int32_t B, int32_t A,
+                   float *grad, float *loss_out) {
+    cnn_grads_f32(P, frames, targets, isw, B, A, grad, loss_out, NULL);
+}
+void orc_cnn_grads_f64(const float *P, const uint8_t *frames, const float *targets, const float *isw, int32_t B, int32_t A,
+                       double *grad, double *loss_out) {
+    cnn_grads_f64(P, frames, targets, isw, B, A, grad, loss_out, NULL);
+}

@@ -269,6 +269,22 @@ def cnn_forward(P, frames, A):
     return q, feat
 
 
+def cnn_grads(P, frames, targets, isw, A, f64=False):
+    """gradient of the reference's loss (q_learning_functions.py:31-39) through the Nature-CNN, every leaf, flat:
+    (grad, loss). f64=True: the double-precision form (tolerance reference)."""
+    frames = u8(frames); B = frames.shape[0]
+    targets = f32(targets); assert targets.shape == (B, A)
+    n = np.asarray(P).size
+    w = None if isw is None else f32(isw)
+    if f64:
+        g = np.empty(n, np.float64); loss = C.c_double(0)
+        lib().orc_cnn_grads_f64(_p(f32(P)), _p(frames), _p(targets), _p(w) if w is not None else None, C.c_int32(B), C.c_int32(A), _p(g), C.byref(loss))
+    else:
+        g = np.empty(n, np.float32); loss = C.c_float(0)
+        lib().orc_cnn_grads(_p(f32(P)), _p(frames), _p(targets), _p(w) if w is not None else None, C.c_int32(B), C.c_int32(A), _p(g), C.byref(loss))
+    return g, loss.value
+
+
 def synth_env(n, D, seed, env_ctr, p_done):
     obs = np.empty((n, D), np.float32); r = np.empty(n, np.float32); d = np.empty(n, np.uint8)
     lib().orc_synth_env(C.c_int32(n), C.c_int32(D), C.c_uint64(seed), C.c_uint64(env_ctr), C.c_float(p_done),

@@ -282,3 +282,37 @@ def test_cnn_oracle_c_vs_numpy_f64():
     o = onp.cnn_param_count(A) - (512 + 1 + 512 * A + A)
     val = f64 @ P[o:o + 512].astype(np.float64) + P[o + 512]
     assert np.allclose(q64.mean(1), val, rtol=1e-9, atol=1e-9)
+
+
+def test_cnn_grad_oracle_finite_differences():
+    """the hand-derived Nature-CNN backward (oracle/dqn_oracle_cnn_grad.inc): its f64 form against central differences of its
+    own f64 loss along sign(gradient) restricted to one leaf at a time, and the f32 fmaf-chain form against the f64 one"""
+    A = 6
+    rng = np.random.default_rng(11)
+    P = onp.cnn_init_params(A, 5)
+    P = (P + 0.01 * rng.standard_normal(P.size)).astype(np.float32)
+    B = 2
+    frames = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+    q, _ = oc.cnn_forward(P, frames, A)
+    targets = (q + rng.standard_normal((B, A)) * np.array([[0.3], [2.5]])).astype(np.float32)     # linear and clipped Huber branches
+    isw = np.array([0.7, 1.0], np.float32)
+    g64, l64 = oc.cnn_grads(P, frames, targets, isw, A, f64=True)
+    g32, l32 = oc.cnn_grads(P, frames, targets, isw, A)
+    assert abs(l32 - l64) < 1e-5 * max(1.0, abs(l64))
+    # leaves: w, b of conv1..3, fc; wv, bv, wa, ba
+    sizes = [8 * 8 * 4 * 32, 32, 4 * 4 * 32 * 64, 64, 3 * 3 * 64 * 64, 64, 3136 * 512, 512, 512, 1, 512 * A, A]
+    assert sum(sizes) == P.size
+    o = 0
+    for n in sizes:
+        leaf64 = g64[o:o + n]
+        scale = np.abs(leaf64).max()
+        assert scale > 0
+        assert np.abs(g32[o:o + n] - leaf64).max() <= 1e-5 * max(scale, 1e-3), (o, n)
+        d = np.zeros(P.size, np.float32)
+        d[o:o + n] = np.where(leaf64 >= 0, 1.0, -1.0).astype(np.float32) * 2.0 ** -18   # along sign(grad): the derivative is sum |g|
+        lp = oc.cnn_grads((P + d).astype(np.float32), frames, targets, isw, A, f64=True)[1]
+        lm = oc.cnn_grads((P - d).astype(np.float32), frames, targets, isw, A, f64=True)[1]
+        step = ((P + d).astype(np.float32).astype(np.float64) - (P - d).astype(np.float32).astype(np.float64))
+        want = float(g64 @ step)
+        assert abs((lp - lm) - want) <= 5e-3 * abs(want) + 1e-9, (o, n, lp - lm, want)
+        o += n
