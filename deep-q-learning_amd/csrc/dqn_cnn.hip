@@ -269,7 +269,7 @@ k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const flo
 // ------------------------------------------------------------------------------------ backward (loss gradient)
 // jax.grad(compute_loss) (General/QLearning/q_learning_functions.py:23, :31-39) through the CNN, hand-derived like the MLP's
 // (dqn_net.hip). Three kinds of kernels:
-//   k_cnn_head_bwd / k_cnn_head_dw   loss, dL/dQ, dueling backward, gradient at the fc pre-activations, head leaves
+//   k_cnn_head_bwd                   loss, dL/dQ, dueling backward, gradient at the fc pre-activations, head-leaf partials
 //   k_cnn_bwd_data<L>                gradient at layer L's INPUT pre-activations: dZ_L . W_L^T as an implicit GEMM in gather form
 //   k_cnn_dw<L>                      dW_L = Patch_L^T . dZ_L (reduction over the output positions), cut into row slices
 // Sums run in another order than the restatement's sample-by-sample accumulation: the bar is 1e-5 of the leaf scale against
@@ -408,9 +408,9 @@ k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, cons
 // WK x WN, each (KT / WK) x (NT / WN) = TK x TN MFMA tiles. The rows of a slice are walked in super-chunks of NSC chunks of MR
 // rows: inside a super-chunk the pipeline is straight-line code (compile-time ring slots), between two the queue drains.
 template <int L> struct DwGeo;
-template <> struct DwGeo<0> { static constexpr int KT = 256, NT = 32, WK = 4, WN = 1, MR = 64, R = 2, NSC = 4; };
-template <> struct DwGeo<1> { static constexpr int KT = 256, NT = 64, WK = 4, WN = 1, MR = 32, R = 2, NSC = 4; };
-template <> struct DwGeo<2> { static constexpr int KT = 192, NT = 64, WK = 2, WN = 2, MR = 32, R = 2, NSC = 4; };
+template <> struct DwGeo<0> { static constexpr int KT = 256, NT = 32, WK = 4, WN = 1, MR = 64, R = 4, NSC = 8; };
+template <> struct DwGeo<1> { static constexpr int KT = 256, NT = 64, WK = 4, WN = 1, MR = 32, R = 4, NSC = 8; };
+template <> struct DwGeo<2> { static constexpr int KT = 192, NT = 64, WK = 2, WN = 2, MR = 32, R = 4, NSC = 8; };
 template <> struct DwGeo<3> { static constexpr int KT = 64, NT = 128, WK = 2, WN = 2, MR = 32, R = 4, NSC = 8; };
 
 // natural-order row images for the dW kernels (the reduction runs over the ROWS of both images)
@@ -566,107 +566,119 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
 }
 
 // Loss, dL/dQ and the dueling backward (as k_bwd_rows in dqn_net.hip: g = w clip(q - target, -1, 1) / B, dv = sum g,
-// dadv = g - mean g), then the gradient at the fc pre-activations: dz4[i][k] = a3 > 0 ? wv[k] dv + sum_j wa[k][j] dadv_j : 0.
-// 16 rows per workgroup; gd[i][0] = dv, gd[i][1 + j] = dadv_j; one loss partial per workgroup.
+// dadv = g - mean g), the gradient at the fc pre-activations dz4[i][k] = a3 > 0 ? wv[k] dv + sum_j wa[k][j] dadv_j : 0, and this
+// workgroup's share of the head leaves: 16 rows per workgroup = one slice of the head slabs
+//   hslab[blk][j][k] = sum_{its rows} a3[i][k] gd[i][j]   (j = 0: val, 1..A: adv),   hbslab[blk][j] = sum gd[i][j]
+// (k_cnn_reduce adds the slices in order); one loss partial per workgroup.
 template <typename TC>
 __global__ void __launch_bounds__(256)
 k_cnn_head_bwd(const float *__restrict__ q, const float *__restrict__ targets, const float *__restrict__ isw, const TC *__restrict__ feat,
-               const float *__restrict__ wht, int A, int B, float *__restrict__ gd, TC *__restrict__ dz4, float *__restrict__ loss_part) {
+               const float *__restrict__ wht, int A, int B, TC *__restrict__ dz4, float *__restrict__ hslab, float *__restrict__ hbslab,
+               float *__restrict__ loss_part) {
     __shared__ float lg[16 * 16], lrow[16];
     const int tid = threadIdx.x, r0 = blockIdx.x * 16;
-    if (tid < 16) {
-        const int i = r0 + tid;
-        float row = 0.0f, gsum = 0.0f, g[16];
-        if (i < B) {
-            const float w = isw ? isw[i] : 1.0f, invB = __fdiv_rn(1.0f, (float)B);
-            for (int j = 0; j < A; ++j) {
-                const float e = q[(long long)i * A + j] - targets[(long long)i * A + j];
-                row = row + huber(e);
-                const float cpd = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
-                g[j] = (w * cpd) * invB;
-                gsum = gsum + g[j];
-            }
-            if (isw) row = w * row;
-            const float gmean = __fdiv_rn(gsum, (float)A);
-            lg[16 * tid] = gsum;
-            for (int j = 0; j < A; ++j) lg[16 * tid + 1 + j] = g[j] - gmean;
-            for (int j = A + 1; j < 16; ++j) lg[16 * tid + j] = 0.0f;
-            for (int j = 0; j < 16; ++j) gd[(long long)i * 16 + j] = lg[16 * tid + j];
-        } else for (int j = 0; j < 16; ++j) lg[16 * tid + j] = 0.0f;
-        lrow[tid] = row;
+    {                                                              // thread (row, j): one Q entry
+        const int row = tid >> 4, j = tid & 15, i = r0 + row;
+        const bool on = i < B && j < A;
+        float e = 0.0f, w = 1.0f;
+        if (on) { e = q[(long long)i * A + j] - targets[(long long)i * A + j]; if (isw) w = isw[i]; }
+        const float cpd = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+        const float g = on ? (w * cpd) * __fdiv_rn(1.0f, (float)B) : 0.0f;
+        float hub = on ? huber(e) : 0.0f, gsum = g;
+        // sums over the 16 lanes of a row in ascending j (the order of the restatement): a serial walk through LDS
+        lg[tid] = g; __syncthreads();
+        if (j == 0) {
+            float s = 0.0f;
+            for (int a = 0; a < A; ++a) s = s + lg[16 * row + a];
+            gsum = s;
+        }
+        __syncthreads();
+        lg[tid] = hub; __syncthreads();
+        if (j == 0) {
+            float s = 0.0f;
+            for (int a = 0; a < A; ++a) s = s + lg[16 * row + a];
+            lrow[row] = (i < B && isw) ? w * s : s;
+        }
+        __syncthreads();
+        gsum = __shfl(gsum, (tid & 48), 64);                       // lane j = 0 of this row (16 lanes per row, 4 rows per wave)
+        const float gmean = __fdiv_rn(gsum, (float)A);
+        if (j < 15) lg[16 * row + 1 + j] = on ? g - gmean : 0.0f;  // gd[row][1 + j] = dadv_j, slots above A stay 0 (all Huber sums are read)
+        if (j == 0) lg[16 * row] = i < B ? gsum : 0.0f;            // gd[row][0] = dv
+        __syncthreads();
     }
-    __syncthreads();
     if (tid == 0) { float s = 0.0f; for (int r = 0; r < 16; ++r) s = s + lrow[r]; loss_part[blockIdx.x] = s; }
+    if (tid < 16) {
+        float s = 0.0f;
+        for (int r = 0; r < 16; ++r) s = s + lg[16 * r + tid];
+        hbslab[(long long)blockIdx.x * 16 + tid] = s;
+    }
     // thread: 2 columns k of all 16 rows
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int k = tid + 256 * kk;
-        float w[16];
-        for (int j = 0; j <= A; ++j) w[j] = wht[j * CNN_F + k];
+        float w[16], acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { w[j] = wht[j * CNN_F + k]; acc[j] = 0.0f; }          // rows above A are 0 in the shadow
+        float x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int i = r0 + r; x[r] = (float)feat[(long long)(i < B ? i : B - 1) * CNN_F + k]; }
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = r0 + r;
-            if (i >= B) break;
             float t = w[0] * lg[16 * r];
-            for (int j = 1; j <= A; ++j) t = fmaf(w[j], lg[16 * r + j], t);
-            const long long o = (long long)i * CNN_F + k;
-            dz4[o] = (float)feat[o] > 0.0f ? (TC)t : (TC)0.0f;
+#pragma unroll
+            for (int j = 1; j < 16; ++j) t = fmaf(w[j], lg[16 * r + j], t);
+            if (i < B) dz4[(long long)i * CNN_F + k] = x[r] > 0.0f ? (TC)t : (TC)0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(x[r], lg[16 * r + j], acc[j]);      // rows past B: gd = 0
         }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hslab[((long long)blockIdx.x * 16 + j) * CNN_F + k] = acc[j];
     }
 }
 
-// head leaves: grad wv[k] = sum_i a3[i][k] dv_i, wa[k][j] = sum_i a3[i][k] dadv_ij (i ascending, one chain per element);
-// bv, ba = column sums of gd. grid: 512 * 16 / 256 blocks (+ 1 for the biases).
-template <typename TC>
+// grad leaf = sum over the slices of its slab, in slice order (deterministic); loss = sum of the head partials / B.
+// A segment is walked four elements per thread where its size and offsets allow; adv > 0 marks the adv-head leaf, whose slab
+// is output-major ([1 + j][k]) while the leaf is [k][j].
+struct CnnSeg { const float *slab; long long n, dst, stride, units; int S, adv; float div; };
+struct CnnSegs { CnnSeg s[12]; int count; };
 __global__ void __launch_bounds__(256)
-k_cnn_head_dw(const TC *__restrict__ feat, const float *__restrict__ gd, int A, int B, float *__restrict__ g_wv, float *__restrict__ g_bv,
-              float *__restrict__ g_wa, float *__restrict__ g_ba) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == CNN_F * 16 / 256) {
-        if (threadIdx.x <= A) {
-            float s = 0.0f;
-            for (int i = 0; i < B; ++i) s = s + gd[(long long)i * 16 + threadIdx.x];
-            if (threadIdx.x == 0) g_bv[0] = s; else g_ba[threadIdx.x - 1] = s;
-        }
-        return;
-    }
-    const int j = t / CNN_F, k = t - j * CNN_F;
-    if (j > A) return;
-    float acc = 0.0f;
-    int i = 0;
-    for (; i + 8 <= B; i += 8) {
-        float x[8], d[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { x[u] = (float)feat[(long long)(i + u) * CNN_F + k]; d[u] = gd[(long long)(i + u) * 16 + j]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fmaf(x[u], d[u], acc);
-    }
-    for (; i < B; ++i) acc = fmaf((float)feat[(long long)i * CNN_F + k], gd[(long long)i * 16 + j], acc);
-    if (j == 0) g_wv[k] = acc; else g_wa[(long long)k * A + (j - 1)] = acc;
-}
-
-// grad leaf = sum over the slices of its slab, in slice order (deterministic); loss = sum of the head partials / B
-struct CnnSeg { const float *slab; long long n, dst; int S; float div; };
-struct CnnSegs { CnnSeg s[8]; };
-__global__ void __launch_bounds__(256)
-k_cnn_reduce(CnnSegs segs, long long total, float *__restrict__ grad, const float *__restrict__ loss_part, int loss_parts, int B, float *__restrict__ loss) {
+k_cnn_reduce(CnnSegs segs, long long total_units, float *__restrict__ grad, const float *__restrict__ loss_part, int loss_parts, int B, float *__restrict__ loss) {
     long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t == 0 && loss) { float s = 0.0f; for (int i = 0; i < loss_parts; ++i) s = s + loss_part[i]; *loss = __fdiv_rn(s, (float)B); }
-    if (t >= total) return;
+    if (t >= total_units) return;
     int g = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) if (t >= segs.s[g].n) { t -= segs.s[g].n; ++g; }
+    for (int i = 0; i + 1 < segs.count; ++i) if (g == i && t >= segs.s[i].units) { t -= segs.s[i].units; ++g; }
     const CnnSeg sg = segs.s[g];
-    const float *p = sg.slab + t;
+    if (sg.units != sg.n) {                                          // four elements per thread
+        const float4 *p = reinterpret_cast<const float4 *>(sg.slab + 4 * t);
+        const long long st4 = sg.stride / 4;
+        float4 acc = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        int s = 0;
+        for (; s + 8 <= sg.S; s += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * st4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x = acc.x + v[u].x; acc.y = acc.y + v[u].y; acc.z = acc.z + v[u].z; acc.w = acc.w + v[u].w; }
+        }
+        for (; s < sg.S; ++s) { const float4 v = p[(long long)s * st4]; acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+        if (sg.div != 1.0f) { acc.x = __fdiv_rn(acc.x, sg.div); acc.y = __fdiv_rn(acc.y, sg.div); acc.z = __fdiv_rn(acc.z, sg.div); acc.w = __fdiv_rn(acc.w, sg.div); }
+        *reinterpret_cast<float4 *>(grad + sg.dst + 4 * t) = acc;
+        return;
+    }
+    const long long src = sg.adv ? (long long)(1 + t % sg.adv) * CNN_F + t / sg.adv : t;
+    const float *p = sg.slab + src;
     float acc = 0.0f;
     int s = 0;
     for (; s + 8 <= sg.S; s += 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * sg.n];
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * sg.stride];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = acc + v[u];
     }
-    for (; s < sg.S; ++s) acc = acc + p[(long long)s * sg.n];
+    for (; s < sg.S; ++s) acc = acc + p[(long long)s * sg.stride];
     grad[sg.dst + t] = sg.div != 1.0f ? __fdiv_rn(acc, sg.div) : acc;
 }
 
@@ -708,16 +720,18 @@ k_cnn_scatter(CnnOffs o, CnnShadows<TC> sh, const float *__restrict__ P) {
 }
 
 // optax adam / adamw element (adam_elem, dqn_net_common.h) + shadow refresh; the step counters live in CnnOptState and are
-// advanced by k_cnn_opt_bump behind this kernel
+// advanced by k_cnn_opt_prep BEFORE the step's Adam kernel (dqn_cnn_update: on the side stream, beside the backward)
 struct CnnOptState { double b1pow, b2pow; int count; float lr; };
+__global__ void k_cnn_opt_prep(CnnOptState *st, float b1, float b2) {
+    st->b1pow *= (double)b1; st->b2pow *= (double)b2; st->count += 1;
+}
 template <typename TC>
 __global__ void __launch_bounds__(256)
 k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, float *P, const float *__restrict__ grad, float *mu, float *nu,
            int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= o.P) return;
-    const double b1p = st->b1pow * (double)b1, b2p = st->b2pow * (double)b2;
-    const AdamCoef c{(float)(1.0 - b1p), (float)(1.0 - b2p), 1.0f - b1, 1.0f - b2, -st->lr};
+    const AdamCoef c{(float)(1.0 - st->b1pow), (float)(1.0 - st->b2pow), 1.0f - b1, 1.0f - b2, -st->lr};
     const float gi = grad[i] * grad_scale;
     const float mm = (b1 * mu[i]) + (c.omb1 * gi);
     const float vv = (b2 * nu[i]) + (c.omb2 * (gi * gi));
@@ -729,9 +743,6 @@ k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, flo
     p = p + (c.neglr * u);
     P[i] = p;
     scatter_shadows<TC>(o, sh, i, p);
-}
-__global__ void k_cnn_opt_bump(CnnOptState *st, float b1, float b2) {
-    st->b1pow *= (double)b1; st->b2pow *= (double)b2; st->count += 1;
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -751,9 +762,10 @@ struct dqn_cnn_handle {
     void *dz[4] = {nullptr};                           // gradients at the layers' pre-activations (same shapes)
     float *q[3] = {nullptr, nullptr, nullptr};         // Q of the three passes of compute_q_targets
     float *scratch = nullptr;
-    float *grad = nullptr, *mu = nullptr, *nu = nullptr, *gd = nullptr, *loss_part = nullptr, *loss = nullptr, *targets = nullptr;
-    float *slab[4] = {nullptr}, *bslab[4] = {nullptr}; int smax[4] = {1, 1, 1, 1};
+    float *grad = nullptr, *mu = nullptr, *nu = nullptr, *loss_part = nullptr, *loss = nullptr, *targets = nullptr;
+    float *slab[4] = {nullptr}, *bslab[4] = {nullptr}, *hslab = nullptr, *hbslab = nullptr; int smax[4] = {1, 1, 1, 1};
     CnnOptState *opt = nullptr;
+    hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
 };
 
@@ -813,7 +825,8 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz);
         sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
     }
-    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 3 * al((size_t)max_batch * 4) + 1024;
+    const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
+    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 3 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
     for (int l = 0; l < 4; ++l) total += 2 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
@@ -827,10 +840,16 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
     for (int l = 0; l < 4; ++l) { h->act[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
     for (int i = 0; i < 3; ++i) h->q[i] = (float *)take(sz_q);
-    h->gd = (float *)take(sz_q); h->targets = (float *)take(sz_q);
+    h->targets = (float *)take(sz_q);
     h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
     h->loss = (float *)take(256); h->opt = (CnnOptState *)take(256);
+    h->hslab = (float *)take(sz_hslab); h->hbslab = (float *)take(sz_hbslab);
     (void)hipMemset(h->arena, 0, total);
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess) {
+        bool ok = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) == hipSuccess;
+        for (int l = 1; l < 4; ++l) ok = ok && hipEventCreateWithFlags(&h->ev_dz[l], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+    } else h->side = nullptr;
     const CnnOptState st0{1.0, 1.0, 0, 3e-4f};
     (void)hipMemcpy(h->opt, &st0, sizeof(st0), hipMemcpyHostToDevice);
     *out = h;
@@ -840,6 +859,9 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
 extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (!h) return DQN_OK;
     (void)hipDeviceSynchronize();
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
+    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->arena) (void)hipFree(h->arena);
     delete h;
     return DQN_OK;
@@ -938,8 +960,9 @@ static void launch_dw(dqn_cnn_handle *h, hipStream_t s, int B, const TI *in, con
     typedef CnnGeo<L> G;
     const int M = B * G::OH * G::OW, rows = dw_rows_per_slice(h, L, M), S = (M + rows - 1) / rows, tiles = dw_shape(L).tiles;
     DQN_LAUNCH((k_cnn_dw<TI, TC, L>), dim3((unsigned)(tiles * S)), dim3(256), 0, s, M, rows, in, dz, h->slab[L], h->bslab[L]);
-    segs.s[nseg++] = CnnSeg{h->slab[L], (long long)h->L[L].K * h->L[L].N, h->L[L].o_w, S, div};
-    segs.s[nseg++] = CnnSeg{h->bslab[L], (long long)h->L[L].N, h->L[L].o_b, S, 1.0f};
+    const long long nw = (long long)h->L[L].K * h->L[L].N, nb = h->L[L].N;
+    segs.s[nseg++] = CnnSeg{h->slab[L], nw, h->L[L].o_w, nw, nw / 4, S, 0, div};
+    segs.s[nseg++] = CnnSeg{h->bslab[L], nb, h->L[L].o_b, nb, nb / 4, S, 0, 1.0f};
 }
 template <typename TC, int L>
 static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
@@ -951,21 +974,33 @@ static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
 
 // backward from the activations the last online forward left in the handle and its predictions q
 template <typename TC>
-static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s) {
+static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt) {
     const int blocks = (B + 15) / 16;
-    hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, h->gd, (TC *)h->dz[3], h->loss_part);
-    hipLaunchKernelGGL((k_cnn_head_dw<TC>), dim3(CNN_F * 16 / 256 + 1), dim3(256), 0, s, (const TC *)h->act[3], h->gd, h->A, B, h->grad + h->o_wv, h->grad + h->o_bv,
-                       h->grad + h->o_wa, h->grad + h->o_ba);
+    hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, (TC *)h->dz[3], h->hslab, h->hbslab,
+                       h->loss_part);
     CnnSegs segs{}; int nseg = 0;
+    segs.s[nseg++] = CnnSeg{h->hslab, CNN_F, h->o_wv, 16 * CNN_F, CNN_F / 4, blocks, 0, 1.0f};
+    segs.s[nseg++] = CnnSeg{h->hbslab, 1, h->o_bv, 16, 1, blocks, 0, 1.0f};
+    segs.s[nseg++] = CnnSeg{h->hslab, (long long)CNN_F * h->A, h->o_wa, 16 * CNN_F, (long long)CNN_F * h->A, blocks, h->A, 1.0f};
+    segs.s[nseg++] = CnnSeg{h->hbslab + 1, h->A, h->o_ba, 16, h->A, blocks, 0, 1.0f};
+    // dW_l needs dZ_l only: layers 3..1 go to the side stream as soon as their dZ exists, the chain dZ4 -> dZ3 -> dZ2 -> dZ1 -> dW_conv1
+    // stays on the caller's stream (fork / join by events: also valid inside a stream capture)
+    hipStream_t sd = h->side ? h->side : s;
+    if (h->side) { (void)hipEventRecord(h->ev_dz[3], s); (void)hipStreamWaitEvent(sd, h->ev_dz[3], 0); }
+    if (prep_opt) hipLaunchKernelGGL(k_cnn_opt_prep, dim3(1), dim3(1), 0, sd, h->opt, h->b1, h->b2);
+    launch_dw<TC, TC, 3>(h, sd, B, (const TC *)h->act[2], (const TC *)h->dz[3], segs, nseg, 1.0f);
     launch_bwd_data<TC, 3>(h, s, B);
-    launch_dw<TC, TC, 3>(h, s, B, (const TC *)h->act[2], (const TC *)h->dz[3], segs, nseg, 1.0f);
+    if (h->side) { (void)hipEventRecord(h->ev_dz[2], s); (void)hipStreamWaitEvent(sd, h->ev_dz[2], 0); }
+    launch_dw<TC, TC, 2>(h, sd, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
     launch_bwd_data<TC, 2>(h, s, B);
-    launch_dw<TC, TC, 2>(h, s, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
+    if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd, h->ev_dz[1], 0); }
+    launch_dw<TC, TC, 1>(h, sd, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
     launch_bwd_data<TC, 1>(h, s, B);
-    launch_dw<TC, TC, 1>(h, s, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
     launch_dw<uint8_t, TC, 0>(h, s, B, frames, (const TC *)h->dz[0], segs, nseg, sizeof(TC) == 2 ? 255.0f : 1.0f);   // bf16 mode multiplies integer pixels
+    if (h->side) { (void)hipEventRecord(h->ev_side, sd); (void)hipStreamWaitEvent(s, h->ev_side, 0); }
     long long total = 0;
-    for (int i = 0; i < nseg; ++i) total += segs.s[i].n;
+    for (int i = 0; i < nseg; ++i) total += segs.s[i].units;
+    segs.count = nseg;
     hipLaunchKernelGGL(k_cnn_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs, total, h->grad, h->loss_part, blocks, B, h->loss);
 }
 
@@ -976,7 +1011,7 @@ extern "C" int dqn_cnn_grads(dqn_cnn_handle *h, const uint8_t *frames, const flo
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t s = (hipStream_t)stream;
     int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, frames, B, h->q[0], stream); if (rc) return rc;
-    if (h->bf16) cnn_backward_t<__bf16>(h, frames, h->q[0], targets, isw, B, s); else cnn_backward_t<float>(h, frames, h->q[0], targets, isw, B, s);
+    if (h->bf16) cnn_backward_t<__bf16>(h, frames, h->q[0], targets, isw, B, s, false); else cnn_backward_t<float>(h, frames, h->q[0], targets, isw, B, s, false);
     CNN_TRY(hipGetLastError());
     if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, s)); CNN_TRY(hipStreamSynchronize(s)); }
     return DQN_OK;
@@ -994,18 +1029,21 @@ extern "C" int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr,
     return DQN_OK;
 }
 
-/* optimizer.update + optax.apply_updates (q_learning_functions.py:24-25) on the gradient buffer; refreshes the shadows */
-extern "C" int dqn_cnn_optimizer_step(dqn_cnn_handle *h, float grad_scale, void *stream) {
-    CNN_REQ(h, "null handle");
-    hipStream_t s = (hipStream_t)stream;
+static int cnn_adam(dqn_cnn_handle *h, float grad_scale, hipStream_t s) {
     const unsigned blocks = (unsigned)((h->P + 255) / 256);
     if (h->bf16) hipLaunchKernelGGL((k_cnn_adam<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
                                     h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
     else hipLaunchKernelGGL((k_cnn_adam<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
                             h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
-    hipLaunchKernelGGL(k_cnn_opt_bump, dim3(1), dim3(1), 0, s, h->opt, h->b1, h->b2);
     CNN_TRY(hipGetLastError());
     return DQN_OK;
+}
+
+/* optimizer.update + optax.apply_updates (q_learning_functions.py:24-25) on the gradient buffer; refreshes the shadows */
+extern "C" int dqn_cnn_optimizer_step(dqn_cnn_handle *h, float grad_scale, void *stream) {
+    CNN_REQ(h, "null handle");
+    hipLaunchKernelGGL(k_cnn_opt_prep, dim3(1), dim3(1), 0, (hipStream_t)stream, h->opt, h->b1, h->b2);
+    return cnn_adam(h, grad_scale, (hipStream_t)stream);
 }
 
 /* train_step (q_learning_functions.py:14-28) */
@@ -1021,9 +1059,9 @@ extern "C" int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t
                               const float *isw, float gamma, int32_t B, float *loss_host, void *stream) {
     int rc = dqn_cnn_q_targets(h, s, a, r, s2, d, gamma, B, h->targets, stream); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st);
+    if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
     CNN_TRY(hipGetLastError());
-    rc = dqn_cnn_optimizer_step(h, 1.0f, stream); if (rc) return rc;
+    rc = cnn_adam(h, 1.0f, st); if (rc) return rc;
     if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
     return DQN_OK;
 }
