@@ -398,26 +398,37 @@ def per_sample_lines(dq, rank):
 
 
 def cnn_lines(dq):
-    """BASELINE.json configs[4] (PongNoFrameskip-v4 shape, 512 envs): the Nature-CNN dueling forward (dqn_cnn.hip, five
-    launches: three convolutions, fc, head) on 512 frame stacks, HIP events around 20 back-to-back forwards"""
+    """BASELINE.json configs[4] (PongNoFrameskip-v4 shape, 512 envs): the Nature-CNN dueling Q-net (dqn_cnn.hip) on 512 frame
+    stacks -- the forward (five launches) and one whole Agent._step on a given minibatch (dqn_cnn_update: three forwards, TD
+    rule, loss gradient through the CNN, AdamW, shadow refresh), HIP events around 20 back-to-back calls"""
     out = {}
     Bc, A_, flop = 512, 6, 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7)
-    frames = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda")
+    bwd = 2 * (2 * (81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7) + 400 * 32 * 256)      # dX and dW per layer; conv1 has no dX
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    frames = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda", generator=g)
+    frames2 = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda", generator=g)
+    act = torch.randint(0, A_, (Bc,), dtype=torch.int32, device="cuda", generator=g)
+    r = torch.randn(Bc, device="cuda", generator=g); d = (torch.rand(Bc, device="cuda", generator=g) < 0.05).float()
     for prec, peak in (("bf16", MFMA_BF16_PEAK_TFLOPS), ("f32", MFMA_F32_PEAK_TFLOPS)):
         e = dq.CnnEngine(num_actions=A_, max_batch=Bc, precision=prec)
-        e.set_params(torch.randn(e.param_count) * 0.02)
+        P = torch.randn(e.param_count) * 0.02
+        e.set_params(P); e.set_params(P, target=True)
         q = torch.empty((Bc, A_), dtype=torch.float32, device="cuda")
-        for _ in range(3):
-            e.forward(frames, out=q)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(20):
-            e.forward(frames, out=q)
-        e1.record(); e1.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 20
-        out[f"cnn_fwd_B{Bc}_{prec}"] = {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": flop * Bc / us / 1e6, "peak": peak,
-                                        "unit": "TFLOP/s", "frac": flop * Bc / us / 1e6 / peak, "traffic": None,
-                                        "note": "BASELINE configs[4] forward only (no CNN backward yet): 5 launches per forward, launch gaps included"}
+        for name, fn, fl, note in (
+                (f"cnn_fwd_B{Bc}_{prec}", lambda: e.forward(frames, out=q), flop,
+                 "BASELINE configs[4] forward: 5 launches, launch gaps included"),
+                (f"cnn_update_B{Bc}_{prec}", lambda: e.update(frames, act, r, frames2, d), 3 * flop + bwd,
+                 "BASELINE configs[4] Agent._step on a given minibatch: 3 forwards + TD + backward (3 dX, 4 dW) + reduce + AdamW, ~27 launches on two streams")):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(20):
+                fn()
+            e1.record(); e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            out[name] = {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": fl * Bc / us / 1e6, "peak": peak,
+                         "unit": "TFLOP/s", "frac": fl * Bc / us / 1e6 / peak, "traffic": None, "note": note}
         e.close()
     return out
 

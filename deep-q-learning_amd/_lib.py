@@ -87,6 +87,7 @@ SIGNATURES = {
     "dqn_cnn_q_targets": [_P, _P, _P, _P, _P, _P, _F, _I32, _P, _P],
     "dqn_cnn_grads": [_P, _P, _P, _P, _I32, _P, _P],
     "dqn_cnn_get_buffer": [_P, C.c_int, _P, C.c_int, _P],
+    "dqn_cnn_buffer": [_P, C.c_int, C.POINTER(_P), C.POINTER(_I64)],
     "dqn_cnn_set_optimizer": [_P, _I32, _F, _F, _F, _F, _F, _P],
     "dqn_cnn_optimizer_step": [_P, _F, _P],
     "dqn_cnn_train_step": [_P, _P, _P, _P, _I32, _P],

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .engine import _ptr
+from .engine import _DevView, _ptr
 
 
 class CnnEngine:
@@ -85,6 +85,14 @@ class CnnEngine:
         L.check(self.lib.dqn_cnn_get_buffer(self.h, {"params": L.BUF_PARAMS, "target": L.BUF_TARGET, "grad": L.BUF_GRAD, "mu": L.BUF_MU, "nu": L.BUF_NU}[which],
                                            _ptr(out), 0, self._s()))
         return out
+
+    def buffer(self, which):
+        """torch view (no copy) of "params" / "target" / "grad" / "mu" / "nu": per-GPU learners all-reduce the "grad" view in
+        place between grads() and optimizer_step(grad_scale=1 / world)"""
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(self.lib.dqn_cnn_buffer(self.h, {"params": L.BUF_PARAMS, "target": L.BUF_TARGET, "grad": L.BUF_GRAD, "mu": L.BUF_MU, "nu": L.BUF_NU}[which],
+                                        C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DevView(p.value, (n.value // 4,), "<f4", self), device=self.device)
 
     def grads(self, frames, targets, isw=None):
         """jax.grad(compute_loss) (q_learning_functions.py:23): fills the gradient buffer, returns the loss"""

@@ -902,6 +902,16 @@ extern "C" int dqn_cnn_get_buffer(dqn_cnn_handle *h, int which_buf, float *dst, 
     return DQN_OK;
 }
 
+/* device pointer of a handle-owned buffer (no copy): the gradient all-reduce of per-GPU learners runs in place on DQN_BUF_GRAD */
+extern "C" int dqn_cnn_buffer(dqn_cnn_handle *h, int which_buf, void **ptr, int64_t *bytes) {
+    CNN_REQ(h && ptr && bytes, "null argument");
+    float *src = which_buf == DQN_BUF_PARAMS ? h->params[0] : which_buf == DQN_BUF_TARGET ? h->params[1] : which_buf == DQN_BUF_GRAD ? h->grad
+               : which_buf == DQN_BUF_MU ? h->mu : which_buf == DQN_BUF_NU ? h->nu : nullptr;
+    CNN_REQ(src, "unknown buffer");
+    *ptr = src; *bytes = h->P * 4;
+    return DQN_OK;
+}
+
 /* Agent._update_target_model (General/QLearning/q_agent.py:143-144) */
 extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
     CNN_REQ(h, "null handle");

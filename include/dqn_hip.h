@@ -259,6 +259,9 @@ int dqn_cnn_grads(dqn_cnn_handle *h, const uint8_t *frames, const float *targets
                   float *loss_host, void *stream);
 /* which_buf: DQN_BUF_PARAMS / _TARGET / _GRAD / _MU / _NU (dqn_cnn_param_count floats each) */
 int dqn_cnn_get_buffer(dqn_cnn_handle *h, int which_buf, float *dst, int dst_is_host, void *stream);
+/* the buffer itself (device pointer, bytes): per-GPU learners all-reduce DQN_BUF_GRAD in place between dqn_cnn_grads and
+ * dqn_cnn_optimizer_step(grad_scale = 1 / world) */
+int dqn_cnn_buffer(dqn_cnn_handle *h, int which_buf, void **ptr, int64_t *bytes);
 /* optax.adam / adamw (Test/lunar_lander.py:48); resets moments and step count */
 int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr, float b1, float b2, float eps, float weight_decay,
                           void *stream);

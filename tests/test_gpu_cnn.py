@@ -209,3 +209,29 @@ def test_cnn_update_tracks_oracle(dq, precision, tol):
             e.sync_target(); Pt = Pc.copy()
             assert np.array_equal(host(e.get_buffer("target")), host(e.get_buffer("params")))
     e.close()
+
+
+def test_cnn_data_parallel_halves(dq):
+    """per-GPU learners with the CNN: two handles take half a minibatch each, the gradient buffers are summed in
+    place (what the all-reduce does) and applied with grad_scale = 1/2 -- the same parameters as one learner on the whole
+    minibatch (1e-5 of the step; summation order differs)"""
+    B = 16
+    P, frames, targets, isw = grad_case(B, 91)
+    full, a, b = (dq.CnnEngine(num_actions=A, max_batch=16, precision="f32") for _ in range(3))
+    for e in (full, a, b):
+        e.set_params(P); e.set_optimizer(lr=1e-3, weight_decay=0.0, adamw=False)
+    full.grads(frames, targets, isw); full.optimizer_step()
+    a.grads(frames[:8], targets[:8], isw[:8]); b.grads(frames[8:], targets[8:], isw[8:])
+    ga, gb = a.buffer("grad"), b.buffer("grad")
+    tot = ga + gb
+    ga.copy_(tot); gb.copy_(tot)
+    a.optimizer_step(grad_scale=0.5); b.optimizer_step(grad_scale=0.5)
+    pf, pa, pb = host(full.get_buffer("params")), host(a.get_buffer("params")), host(b.get_buffer("params"))
+    assert np.array_equal(pa, pb)
+    gf = host(full.get_buffer("grad"))
+    assert np.abs(host(tot) * 0.5 - gf).max() <= 1e-5 * np.abs(gf).max()
+    moved = np.abs(pf - P) > 0
+    # Adam's first step is lr * g / (|g| + eps): only elements whose gradient is within the summation noise of 0 may differ
+    assert moved.mean() > 0.3 and np.mean(np.abs(pa - pf) > 2e-5) < 1e-3        # (inputs that are 0 for all 16 samples leave their fc rows untouched)
+    for e in (full, a, b):
+        e.close()
