@@ -407,63 +407,78 @@ k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, cons
 // dW geometry of layer L: workgroup = (k-tile of KT rows of dW) x (n-tile of NT columns) x (slice of the rows m); four waves as
 // WK x WN, each (KT / WK) x (NT / WN) = TK x TN MFMA tiles. The rows of a slice are walked in super-chunks of NSC chunks of MR
 // rows: inside a super-chunk the pipeline is straight-line code (compile-time ring slots), between two the queue drains.
+// Both operands have the reduction index m as their ROW index in memory, MFMA wants it along the lane's registers:
+//   f32 : row-major LDS images [m][k], [m][n]; a lane feeds ONE element per 32x32x2 MFMA: scalar reads, consecutive lanes =
+//         consecutive words, conflict-free. MR = 32 (64 for conv1).
+//   bf16: TRANSPOSED images [k][m], [n][m], written two bytes at a time -- the pieces are dealt so that the lanes of a wave hold
+//         64 consecutive rows m of the same 8 columns, i.e. every 2-byte store instruction covers 128 contiguous bytes -- and
+//         read as 16-byte fragments (8 consecutive m of one k) like the forward kernel's. MR = 64. (The first version
+//         gathered the 8 rows with ds_read_u16 from row-major images: 24 LDS instructions per two MFMAs.)
 template <int L> struct DwGeo;
-template <> struct DwGeo<0> { static constexpr int KT = 256, NT = 32, WK = 4, WN = 1, MR = 64, R = 4, NSC = 8; };
-template <> struct DwGeo<1> { static constexpr int KT = 256, NT = 64, WK = 4, WN = 1, MR = 32, R = 4, NSC = 8; };
-template <> struct DwGeo<2> { static constexpr int KT = 192, NT = 64, WK = 2, WN = 2, MR = 32, R = 4, NSC = 8; };
-template <> struct DwGeo<3> { static constexpr int KT = 64, NT = 128, WK = 2, WN = 2, MR = 32, R = 4, NSC = 8; };
+template <> struct DwGeo<0> { static constexpr int KT = 256, NT = 32, WK = 4, WN = 1, MRF = 64, R = 4, NSC = 8; };
+template <> struct DwGeo<1> { static constexpr int KT = 256, NT = 64, WK = 4, WN = 1, MRF = 32, R = 4, NSC = 8; };
+template <> struct DwGeo<2> { static constexpr int KT = 192, NT = 64, WK = 2, WN = 2, MRF = 32, R = 4, NSC = 8; };
+template <> struct DwGeo<3> { static constexpr int KT = 64, NT = 128, WK = 2, WN = 2, MRF = 32, R = 4, NSC = 8; };
+template <typename TC, int L> struct DwRows { static constexpr int MR = sizeof(TC) == 2 ? 64 : DwGeo<L>::MRF; };
 
-// natural-order row images for the dW kernels (the reduction runs over the ROWS of both images)
-template <typename TR>
-__device__ __forceinline__ void commit_row_piece(__bf16 *dst, const TR &raw) {
-    if constexpr (__is_same(TR, bf16x8c)) *reinterpret_cast<bf16x8c *>(dst) = raw;
-    else {
-        const uint32_t w[2] = {raw.x, raw.y};
-        bf16x8c a;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = (__bf16)(float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-        *reinterpret_cast<bf16x8c *>(dst) = a;
-    }
-}
+// f32: natural-order row images
 template <typename TR>
 __device__ __forceinline__ void commit_row_piece(float *dst, const TR &raw, const float *lut) {
     float v[8]; piece_f32(raw, lut, v);
     *reinterpret_cast<float4 *>(dst) = float4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<float4 *>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
 }
+// bf16: the 8 elements of a piece go to 8 rows of the transposed image, column m
+template <typename TR>
+__device__ __forceinline__ void commit_col_piece(__bf16 *dst, int ls, const TR &raw) {
+    bf16x8c a;
+    if constexpr (__is_same(TR, bf16x8c)) a = raw;
+    else {
+        const uint32_t w[2] = {raw.x, raw.y};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (__bf16)(float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i * ls] = a[i];
+}
 
 template <typename TI, typename TC, int L>
 __global__ void __launch_bounds__(256)
 k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restrict__ dz, float *__restrict__ slab, float *__restrict__ bslab) {
     typedef CnnGeo<L> G; typedef DwGeo<L> D;
-    constexpr int KT = D::KT, NT = D::NT, WK = D::WK, WN = D::WN, MR = D::MR, R = D::R, NSC = D::NSC;
+    constexpr bool TR = sizeof(TC) == 2;                              // transposed images
+    constexpr int KT = D::KT, NT = D::NT, WK = D::WK, WN = D::WN, MR = DwRows<TC, L>::MR, R = D::R, NSC = D::NSC;
     constexpr int K = G::KH * G::KW * G::IC, N = G::OC, ROWLEN = G::KW * G::IC, KTILES = K / KT, NTILES = N / NT;
     constexpr int TK = KT / WK / 32, TN = NT / WN / 32;
-    constexpr int PAD = sizeof(TC) == 2 ? 8 : 4, LSA = KT + PAD, LSB = NT + PAD;
-    constexpr int APR = KT / 8, BPR = NT / 8;                         // pieces per image row
+    constexpr int LSA = TR ? MR + 8 : KT + 4, LSB = TR ? MR + 8 : NT + 4;      // row length of the images
+    constexpr int APR = KT / 8, BPR = NT / 8;                         // pieces per row m
     constexpr int APT = MR * APR / 256, BPT = MR * BPR / 256;
-    constexpr int LBUF = sizeof(TC) == 2 ? 2 : 1;
+    constexpr int LBUF = TR ? 2 : 1;
     static_assert(WK * WN == 4 && K % KT == 0 && N % NT == 0 && (KT % ROWLEN == 0 || ROWLEN % KT == 0), "tile shape");
-    static_assert(MR * APR % 256 == 0 && MR * BPR % 256 == 0 && NSC % R == 0 && TK >= 1 && TN >= 1, "piece split");
+    static_assert(MR * APR % 256 == 0 && MR * BPR % 256 == 0 && NSC % R == 0 && TK >= 1 && TN >= 1 && 256 % MR == 0, "piece split");
     typedef typename RawPiece<TI>::t RA;
     typedef typename RawPiece<TC>::t RB;
-    __shared__ __attribute__((aligned(16))) TC lA[LBUF * MR * LSA];
-    __shared__ __attribute__((aligned(16))) TC lB[LBUF * MR * LSB];
+    __shared__ __attribute__((aligned(16))) TC lA[LBUF * (TR ? KT * LSA : MR * LSA)];
+    __shared__ __attribute__((aligned(16))) TC lB[LBUF * (TR ? NT * LSB : MR * LSB)];
+    constexpr int ASZ = TR ? KT * LSA : MR * LSA, BSZ = TR ? NT * LSB : MR * LSB;
     __shared__ float lut[(sizeof(TI) == 1 && sizeof(TC) == 4) ? 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave / WN, wn = wave % WN, hi = lane >> 5, c = lane & 31;
     if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) { lut[tid] = __fdiv_rn((float)tid, 255.0f); __syncthreads(); }
     const int tile = blockIdx.x % (KTILES * NTILES), slice = blockIdx.x / (KTILES * NTILES);
     const int kt0 = (tile / NTILES) * KT, n0 = (tile % NTILES) * NT;
     const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
-    // this thread's pieces: image row and offset inside the patch row / the dZ row
-    int arow[APT], akoff[APT], brow[BPT], bcol[BPT];
+    // this thread's pieces: image row m and 8-column group. f32: consecutive threads = consecutive column groups of a row (one
+    // row = one contiguous run); bf16: consecutive threads = consecutive rows of the same column group (see above)
+    int arow[APT], akp[APT], akoff[APT], brow[BPT], bkp[BPT];
 #pragma unroll
     for (int u = 0; u < APT; ++u) {
-        const int q = tid + 256 * u, kp = kt0 + 8 * (q % APR), kh = kp / ROWLEN;
-        arow[u] = q / APR; akoff[u] = kh * (G::IW * G::IC) + (kp - kh * ROWLEN);
+        const int q = tid + 256 * u;
+        arow[u] = TR ? q % MR : q / APR; akp[u] = TR ? q / MR : q % APR;
+        const int kp = kt0 + 8 * akp[u], kh = kp / ROWLEN;
+        akoff[u] = kh * (G::IW * G::IC) + (kp - kh * ROWLEN);
     }
 #pragma unroll
-    for (int u = 0; u < BPT; ++u) { const int q = tid + 256 * u; brow[u] = q / BPR; bcol[u] = 8 * (q % BPR); }
+    for (int u = 0; u < BPT; ++u) { const int q = tid + 256 * u; brow[u] = TR ? q % MR : q / BPR; bkp[u] = TR ? q / MR : q % BPR; }
     RA ra[R][APT]; RB rb[R][BPT];
     auto request = [&](int slot, int mc) {                             // mc: first row of the chunk
 #pragma unroll
@@ -475,20 +490,20 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
 #pragma unroll
         for (int u = 0; u < BPT; ++u) {
             const int mm = mc + brow[u];
-            const RB v = load_piece<TC>(dz + (long long)(mm < M ? mm : M - 1) * N + n0 + bcol[u]);
+            const RB v = load_piece<TC>(dz + (long long)(mm < M ? mm : M - 1) * N + n0 + 8 * bkp[u]);
             rb[slot][u] = mm < m_end ? v : zero_piece<RB>();           // rows past the slice contribute nothing
         }
     };
     auto commit = [&](int slot, int buf) {
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
-            TC *dst = lA + buf * (MR * LSA) + arow[u] * LSA + 8 * ((tid + 256 * u) % APR);
-            if constexpr (sizeof(TC) == 2) commit_row_piece(dst, ra[slot][u]); else commit_row_piece(dst, ra[slot][u], lut);
+            if constexpr (TR) commit_col_piece(lA + buf * ASZ + 8 * akp[u] * LSA + arow[u], LSA, ra[slot][u]);
+            else commit_row_piece(lA + buf * ASZ + arow[u] * LSA + 8 * akp[u], ra[slot][u], lut);
         }
 #pragma unroll
         for (int u = 0; u < BPT; ++u) {
-            TC *dst = lB + buf * (MR * LSB) + brow[u] * LSB + bcol[u];
-            if constexpr (sizeof(TC) == 2) commit_row_piece(dst, rb[slot][u]); else commit_row_piece(dst, rb[slot][u], nullptr);
+            if constexpr (TR) commit_col_piece(lB + buf * BSZ + 8 * bkp[u] * LSB + brow[u], LSB, rb[slot][u]);
+            else commit_row_piece(lB + buf * BSZ + brow[u] * LSB + 8 * bkp[u], rb[slot][u], nullptr);
         }
     };
     f32x16c acc[TK][TN];
@@ -500,30 +515,37 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float bsum = 0.0f;
     auto multiply = [&](int buf) {
-        const TC *a = lA + buf * (MR * LSA) + (wk * TK * 32 + c), *b = lB + buf * (MR * LSB) + (wn * TN * 32 + c);
         if (tile / NTILES == 0 && tid < NT) {                          // bias gradient: column sums of dZ (k-tile 0 only)
-            const TC *col = lB + buf * (MR * LSB) + tid;
+            if constexpr (TR) {
+                const TC *row = lB + buf * BSZ + tid * LSB;
+#pragma unroll
+                for (int r = 0; r < MR; r += 8) {
+                    const bf16x8c v = *reinterpret_cast<const bf16x8c *>(row + r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum = bsum + (float)v[e];
+                }
+            } else {
+                const TC *col = lB + buf * BSZ + tid;
 #pragma unroll 8
-            for (int r = 0; r < MR; ++r) bsum = bsum + (float)col[r * LSB];
+                for (int r = 0; r < MR; ++r) bsum = bsum + (float)col[r * LSB];
+            }
         }
-        if constexpr (sizeof(TC) == 2) {
+        if constexpr (TR) {
+            const TC *a = lA + buf * ASZ + (wk * TK * 32 + c) * LSA + 8 * hi, *b = lB + buf * BSZ + (wn * TN * 32 + c) * LSB + 8 * hi;
 #pragma unroll
             for (int s = 0; s < MR / 16; ++s) {
                 bf16x8c fa[TK], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TK; ++i)
+                for (int i = 0; i < TK; ++i) fa[i] = *reinterpret_cast<const bf16x8c *>(a + 32 * i * LSA + 16 * s);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) fa[i][e] = a[(16 * s + 8 * hi + e) * LSA + 32 * i];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) fb[j][e] = b[(16 * s + 8 * hi + e) * LSB + 32 * j];
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8c *>(b + 32 * j * LSB + 16 * s);
 #pragma unroll
                 for (int i = 0; i < TK; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         } else {
+            const TC *a = lA + buf * ASZ + (wk * TK * 32 + c), *b = lB + buf * BSZ + (wn * TN * 32 + c);
 #pragma unroll 4
             for (int s = 0; s < MR / 2; ++s) {
                 float fa[TK], fb[TN];
@@ -775,13 +797,13 @@ static LayerShape cnn_shape(int layer) {
     switch (layer) { case 0: return shape_of<0>(); case 1: return shape_of<1>(); case 2: return shape_of<2>(); default: return shape_of<3>(); }
 }
 struct DwShape { int tiles, unit; };                    // (k-tiles x n-tiles) of DwGeo<l>; rows of one super-chunk
-template <int L> static DwShape dw_shape_of() { typedef CnnGeo<L> G; typedef DwGeo<L> D; return DwShape{(G::KH * G::KW * G::IC / D::KT) * (G::OC / D::NT), D::NSC * D::MR}; }
-static DwShape dw_shape(int layer) {
-    switch (layer) { case 0: return dw_shape_of<0>(); case 1: return dw_shape_of<1>(); case 2: return dw_shape_of<2>(); default: return dw_shape_of<3>(); }
+template <int L> static DwShape dw_shape_of(bool bf16) { typedef CnnGeo<L> G; typedef DwGeo<L> D; return DwShape{(G::KH * G::KW * G::IC / D::KT) * (G::OC / D::NT), D::NSC * (bf16 ? DwRows<__bf16, L>::MR : DwRows<float, L>::MR)}; }
+static DwShape dw_shape(int layer, bool bf16) {
+    switch (layer) { case 0: return dw_shape_of<0>(bf16); case 1: return dw_shape_of<1>(bf16); case 2: return dw_shape_of<2>(bf16); default: return dw_shape_of<3>(bf16); }
 }
 // rows of layer l's dW are cut into at most smax[l] slices of whole super-chunks
 static int dw_rows_per_slice(const dqn_cnn_handle *h, int l, long long M) {
-    const DwShape d = dw_shape(l);
+    const DwShape d = dw_shape(l, h->bf16);
     const long long per = (M + (long long)h->smax[l] * d.unit - 1) / ((long long)h->smax[l] * d.unit);
     return (int)(per < 1 ? 1 : per) * d.unit;
 }
@@ -812,7 +834,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         const LayerShape g = cnn_shape(l);
         h->L[l] = CnnLayer{g.K, g.OC, p, p + (long long)g.K * g.OC};
         p += (long long)g.K * g.OC + g.OC;
-        const int t = dw_shape(l).tiles;
+        const int t = dw_shape(l, h->bf16).tiles;
         h->smax[l] = t >= h->num_cus ? 1 : (t > h->num_cus / 2 ? 2 : h->num_cus / t);
     }
     h->o_wv = p; p += 512; h->o_bv = p; p += 1; h->o_wa = p; p += 512ll * h->A; h->o_ba = p; p += h->A; h->P = p;
@@ -968,7 +990,7 @@ extern "C" int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int3
 template <typename TI, typename TC, int L>
 static void launch_dw(dqn_cnn_handle *h, hipStream_t s, int B, const TI *in, const TC *dz, CnnSegs &segs, int &nseg, float div) {
     typedef CnnGeo<L> G;
-    const int M = B * G::OH * G::OW, rows = dw_rows_per_slice(h, L, M), S = (M + rows - 1) / rows, tiles = dw_shape(L).tiles;
+    const int M = B * G::OH * G::OW, rows = dw_rows_per_slice(h, L, M), S = (M + rows - 1) / rows, tiles = dw_shape(L, h->bf16).tiles;
     DQN_LAUNCH((k_cnn_dw<TI, TC, L>), dim3((unsigned)(tiles * S)), dim3(256), 0, s, M, rows, in, dz, h->slab[L], h->bslab[L]);
     const long long nw = (long long)h->L[L].K * h->L[L].N, nb = h->L[L].N;
     segs.s[nseg++] = CnnSeg{h->slab[L], nw, h->L[L].o_w, nw, nw / 4, S, 0, div};

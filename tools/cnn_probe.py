@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import deep_q_learning_amd as dq
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="bf16"); ap.add_argument("--batch", type=int, default=512); ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--mode", default="forward")
+ap.add_argument("--mode", default="forward"); ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
 a = ap.parse_args()
 B = a.batch
 e = dq.CnnEngine(num_actions=6, max_batch=B, precision=a.precision)
@@ -23,6 +23,15 @@ q = torch.empty((B, 6), dtype=torch.float32, device="cuda")
 step = (lambda: e.forward(frames, out=q)) if a.mode == "forward" else (lambda: e.update(frames, act, r, frames2, d))
 for _ in range(3):
     step()
+if a.graph:
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step(); torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=st):
+            step()
+    eager, step = step, g_.replay
+    step(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
 for _ in range(a.reps):
