@@ -34,10 +34,23 @@ typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 //   fc     M =      B, K = 3136 (49),      N = 512   32 x 32 from 16 x 16 MFMA tiles: at B = 512 that is 256 workgroups, and in
 //          f32 mode the k-ascending chain of 16x16x4 is 784 MFMAs x 32 cycles (the 32x32x2 chain would be 1568 x 64)
 template <int L> struct CnnGeo;
-template <> struct CnnGeo<0> { static constexpr int IH = 84, IW = 84, IC = 4, OH = 20, OW = 20, OC = 32, KH = 8, KW = 8, S = 4, MT = 32, WM = 4, WN = 1, R = 4; };
-template <> struct CnnGeo<1> { static constexpr int IH = 20, IW = 20, IC = 32, OH = 9, OW = 9, OC = 64, KH = 4, KW = 4, S = 2, MT = 32, WM = 2, WN = 2, R = 4; };
-template <> struct CnnGeo<2> { static constexpr int IH = 9, IW = 9, IC = 64, OH = 7, OW = 7, OC = 64, KH = 3, KW = 3, S = 1, MT = 32, WM = 2, WN = 2, R = 3; };
-template <> struct CnnGeo<3> { static constexpr int IH = 1, IW = 1, IC = 3136, OH = 1, OW = 1, OC = 512, KH = 1, KW = 1, S = 1, MT = 16, WM = 2, WN = 2, R = 7; };
+template <> struct CnnGeo<0> { static constexpr int IH = 84, IW = 84, IC = 4, OH = 20, OW = 20, OC = 32, KH = 8, KW = 8, S = 4; };
+template <> struct CnnGeo<1> { static constexpr int IH = 20, IW = 20, IC = 32, OH = 9, OW = 9, OC = 64, KH = 4, KW = 4, S = 2; };
+template <> struct CnnGeo<2> { static constexpr int IH = 9, IW = 9, IC = 64, OH = 7, OW = 7, OC = 64, KH = 3, KW = 3, S = 1; };
+template <> struct CnnGeo<3> { static constexpr int IH = 1, IW = 1, IC = 3136, OH = 1, OW = 1, OC = 512, KH = 1, KW = 1, S = 1; };
+// Tile shape of the forward kernel, variant V. Workgroup tile = (MT WM TM) rows x (MT WN TN) columns: four waves as WM x WN,
+// each TM x TN MFMA tiles of MT x MT; R = depth of the register prefetch ring.
+//   V = 0 (small batches: many workgroups, one MFMA tile per wave -- the shapes in the table above)
+//   V = 1 (fc layer, bf16 mode, B >= 8192 = 256 workgroups): 2 x 2 MFMA tiles per wave, 128 x 128 workgroup tile -- 88 -> 45 us at B = 8192.
+//         The same idea on the convolutions (256-row tiles, 2 x 2 tiles per wave, one workgroup per CU) was 30-80 % SLOWER than
+//         V = 0 at B = 8192: those kernels are bound by staging (L2 -> registers -> LDS, 11 TB/s of L2 reads at B = 8192, the
+//         4x im2col expansion included), and four small workgroups per CU overlap it where one large one serialises it
+template <int L, int V> struct CnnTile;
+template <> struct CnnTile<0, 0> { static constexpr int MT = 32, WM = 4, WN = 1, TM = 1, TN = 1, R = 4; };
+template <> struct CnnTile<1, 0> { static constexpr int MT = 32, WM = 2, WN = 2, TM = 1, TN = 1, R = 4; };
+template <> struct CnnTile<2, 0> { static constexpr int MT = 32, WM = 2, WN = 2, TM = 1, TN = 1, R = 3; };
+template <> struct CnnTile<3, 0> { static constexpr int MT = 16, WM = 2, WN = 2, TM = 1, TN = 1, R = 7; };
+template <> struct CnnTile<3, 1> { static constexpr int MT = 32, WM = 2, WN = 2, TM = 2, TN = 2, R = 4; };
 
 constexpr int KC = 64;        // k-chunk (a multiple of 8: an 8-element piece never crosses a patch row)
 constexpr int CNN_F = 512;    // fc width = the heads' K
@@ -101,16 +114,16 @@ __device__ __forceinline__ void commit_piece(float *row, int j, const TR &raw, c
 // up front, keeps a single buffer and more workgroups per CU). All slot indices are compile-time, so every s_waitcnt counts the loads of
 // the newer slots instead of draining the queue. Workgroups are numbered so that the ones an XCD receives (id mod 8) are
 // neighbours in m (shared patch rows / weight columns stay in that XCD's L2).
-template <typename TI, typename TC, int L>
+template <typename TI, typename TC, int L, int V>
 __global__ void __launch_bounds__(256)
 k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out) {
-    typedef CnnGeo<L> G;
-    constexpr int MT = G::MT, WM = G::WM, WN = G::WN, R = G::R;
-    constexpr int BM = MT * WM, BN = MT * WN, K = G::KH * G::KW * G::IC, ROWLEN = G::KW * G::IC, NCH = K / KC, NIT = NCH / R;
+    typedef CnnGeo<L> G; typedef CnnTile<L, V> T;
+    constexpr int MT = T::MT, WM = T::WM, WN = T::WN, TM = T::TM, TN = T::TN, R = T::R;
+    constexpr int BM = MT * WM * TM, BN = MT * WN * TN, K = G::KH * G::KW * G::IC, ROWLEN = G::KW * G::IC, NCH = K / KC;
     constexpr int LS = KC + (sizeof(TC) == 2 ? 8 : 4);
     constexpr int LBUF = L == 0 ? 1 : 2;
-    constexpr int APT = BM * 8 / 256, BPT = BN * 8 / 256;
-    static_assert(WM * WN == 4 && K % KC == 0 && NCH % R == 0 && G::OC % BN == 0 && ROWLEN % 8 == 0 && APT >= 1 && BPT >= 1, "tile shape");
+    constexpr int APT = BM * 8 / 256, BPT = BN * 8 / 256, NACC = MT == 32 ? 16 : 4;
+    static_assert(WM * WN == 4 && K % KC == 0 && R <= NCH && G::OC % BN == 0 && ROWLEN % 8 == 0 && APT >= 1 && BPT >= 1, "tile shape");
     typedef typename RawPiece<TI>::t RA;
     typedef typename RawPiece<TC>::t RB;
     __shared__ __attribute__((aligned(16))) TC lA[LBUF * BM * LS];
@@ -149,40 +162,54 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const f
 #pragma unroll
         for (int u = 0; u < BPT; ++u) commit_piece<MT>(b + 32 * u * LS, pj, rb[slot][u], lut);
     };
-    typedef float accv __attribute__((ext_vector_type(MT == 32 ? 16 : 4)));
-    accv acc;
+    typedef float accv __attribute__((ext_vector_type(NACC)));
+    accv acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[r] = 0.0f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.0f;
     const int hi = lane / MT, c = lane % MT;                                           // MT = 32: half h; MT = 16: k-group g
     auto multiply = [&](int buf) {
-        const TC *ar = lA + buf * (BM * LS) + (MT * wm + c) * LS, *br = lB + buf * (BN * LS) + (MT * wn + c) * LS;
-        if constexpr (sizeof(TC) == 2 && MT == 32) {
+        const TC *ar = lA + buf * (BM * LS) + (MT * TM * wm + c) * LS, *br = lB + buf * (BN * LS) + (MT * TN * wn + c) * LS;
+        if constexpr (sizeof(TC) == 2) {
+            constexpr int KS = MT == 32 ? 16 : 32;                                     // k per MFMA
 #pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8c *>(ar + 16 * ks + 8 * hi),
-                                                              *reinterpret_cast<const bf16x8c *>(br + 16 * ks + 8 * hi), acc, 0, 0, 0);
-        } else if constexpr (sizeof(TC) == 2) {
+            for (int ks = 0; ks < KC / KS; ++ks) {
+                bf16x8c fa[TM], fb[TN];
 #pragma unroll
-            for (int ks = 0; ks < KC / 32; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8c *>(ar + 32 * ks + 8 * hi),
-                                                              *reinterpret_cast<const bf16x8c *>(br + 32 * ks + 8 * hi), acc, 0, 0, 0);
-        } else if constexpr (MT == 32) {
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8c *>(ar + MT * i * LS + KS * ks + 8 * hi);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {                                               // k = 2 (4q + i) + h: ascending chain
-                const float4 a = *reinterpret_cast<const float4 *>(ar + 32 * hi + 4 * q), b = *reinterpret_cast<const float4 *>(br + 32 * hi + 4 * q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8c *>(br + MT * j * LS + KS * ks + 8 * hi);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (MT == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
             }
         } else {
+            constexpr int QN = MT == 32 ? 8 : 4, HO = MT == 32 ? 32 : 16;              // 16-byte reads per chunk; offset of the lane's k-class
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                               // k = 4 (4q + i) + g: ascending chain
-                const float4 a = *reinterpret_cast<const float4 *>(ar + 16 * hi + 4 * q), b = *reinterpret_cast<const float4 *>(br + 16 * hi + 4 * q);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+            for (int q = 0; q < QN; ++q) {                                             // k ascending within every accumulator's chain
+                float4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(ar + MT * i * LS + HO * hi + 4 * q);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4 *>(br + MT * j * LS + HO * hi + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = e == 0 ? fa[i].x : e == 1 ? fa[i].y : e == 2 ? fa[i].z : fa[i].w;
+                            const float bv = e == 0 ? fb[j].x : e == 1 ? fb[j].y : e == 2 ? fb[j].z : fb[j].w;
+                            if constexpr (MT == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
             }
         }
     };
@@ -190,35 +217,29 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const f
     for (int r = 0; r < R; ++r) request(r, r);
     if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) __syncthreads();                 // the table, before the first commit reads it
 #pragma unroll                      // fully: a rolled loop turns the ring into register copies that wait for the loads just issued
-    for (int it = 0; it < NIT - 1; ++it) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int kc = it * R + r, buf = LBUF == 2 ? (kc & 1) : 0;
-            commit(r, buf);
-            request(r, kc + R);
-            __syncthreads();
-            multiply(buf);
-            if constexpr (LBUF == 1) __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int kc = (NIT - 1) * R + r, buf = LBUF == 2 ? (kc & 1) : 0;
-        commit(r, buf);
+    for (int kc = 0; kc < NCH; ++kc) {
+        const int buf = LBUF == 2 ? (kc & 1) : 0;
+        commit(kc % R, buf);
+        if (kc + R < NCH) request(kc % R, kc + R);
         __syncthreads();
         multiply(buf);
         if constexpr (LBUF == 1) __syncthreads();
     }
-    const int n = n0 + MT * wn + c;
-    const float bv = bias[n];
 #pragma unroll
-    for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) {
-        const int mm = m0 + MT * wm + (MT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * hi : 4 * hi + r);
-        if (mm < M) {
-            float v = acc[r] + bv;
-            v = v > 0.0f ? v : 0.0f;
-            out[(long long)mm * G::OC + n] = (TC)v;
-        }
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + MT * (TN * wn + j) + c;
+        const float bv = bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                const int mm = m0 + MT * (TM * wm + i) + (MT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * hi : 4 * hi + r);
+                if (mm < M) {
+                    float v = acc[i][j][r] + bv;
+                    v = v > 0.0f ? v : 0.0f;
+                    out[(long long)mm * G::OC + n] = (TC)v;
+                }
+            }
     }
 }
 
@@ -946,8 +967,20 @@ extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
 template <typename TI, typename TC, int L>
 static void launch_layer(hipStream_t s, int B, const TI *in, const TC *wt, const float *bias, TC *out) {
     typedef CnnGeo<L> G;
-    const int M = B * G::OH * G::OW, BM = G::MT * G::WM, BN = G::MT * G::WN;
-    DQN_LAUNCH((k_cnn_layer<TI, TC, L>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
+    const int M = B * G::OH * G::OW;
+    if constexpr (sizeof(TC) == 2 && L == 3) {
+        if (B >= 8192) {
+            typedef CnnTile<L, 1> T;
+            const int BM = T::MT * T::WM * T::TM, BN = T::MT * T::WN * T::TN;
+            DQN_LAUNCH((k_cnn_layer<TI, TC, L, 1>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
+            return;
+        }
+    }
+    {
+        typedef CnnTile<L, 0> T;
+        const int BM = T::MT * T::WM * T::TM, BN = T::MT * T::WN * T::TN;
+        DQN_LAUNCH((k_cnn_layer<TI, TC, L, 0>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
+    }
 }
 
 template <typename TC>

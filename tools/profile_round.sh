@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (GPU box): bash tools/profile_round.sh <tag>   -- every rocprofv3 pass whose summary is committed under profiles/:
 #   kernel-trace + stats of bench.py; FETCH_SIZE / WRITE_SIZE of the bench kernels and of the stand-alone sampler (separate
-#   passes); one MFMA / wave-state counter pass for the bench kernels and one for the large-batch kernels; batch sweeps.
+#   passes); one MFMA / wave-state counter pass for the bench kernels, the large-batch kernels and the CNN update (bf16, f32);
+#   per-kernel medians of the CNN forward / update (kernel trace); batch sweeps.
 tag=$1
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out
 sed -i 's/--no-cpu-baseline --profile-steps 5/--no-cpu-baseline --no-secondary --profile-steps 5/; s/--steps 200 --warmup 20 --no-cpu-baseline --profile-steps 2/--steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2/' $R/tools/prof.sh $R/tools/prof_pmc.sh
@@ -10,6 +11,10 @@ bash $R/tools/prof_pmc.sh $tag 2>&1 | tail -8
 bash $R/tools/prof_pmc_sample.sh $tag 2>&1 | tail -7
 bash $R/tools/prof_pmc_mfma.sh ${tag}_bench $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2 2>&1 | grep "^k_\|rc=" | cut -c1-330
 bash $R/tools/prof_pmc_mfma.sh ${tag}_big $R/tools/big_probe.py --mode update --log2 17 --reps 6 2>&1 | grep "^k_big\|rc=" | cut -c1-330
+bash $R/tools/prof_pmc_mfma.sh ${tag}_cnn $R/tools/cnn_probe.py --mode update --reps 6 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
+bash $R/tools/prof_pmc_mfma.sh ${tag}_cnnf32 $R/tools/cnn_probe.py --mode update --reps 6 --precision f32 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
+(bash $R/tools/kt_cnn.sh ${tag}_ub --mode update; bash $R/tools/kt_cnn.sh ${tag}_uf --mode update --precision f32; bash $R/tools/kt_cnn.sh ${tag}_fb --mode forward; bash $R/tools/kt_cnn.sh ${tag}_ff --mode forward --precision f32) > $out/cnn_$tag.txt 2>&1
+tail -3 $out/cnn_$tag.txt
 cd $R
 python tools/per_sample_probe.py --json $out/probe_$tag.json 2>&1 | tail -8
 python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
