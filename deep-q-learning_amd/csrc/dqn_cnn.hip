@@ -397,6 +397,22 @@ k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, cons
     const int hi = lane >> 5, c = lane & 31;
 #pragma unroll
     for (int r = 0; r < R; ++r) request(r, r);
+    // the ReLU gates of this lane's 16 outputs: requested here, behind the first operand loads, consumed in the epilogue (read
+    // inside the store loop they were 16 serial round trips per workgroup: 3.4x the time of the forward kernel of the same shape)
+    const int n = n0 + MT * wn + c;
+    auto out_off = [&](int r) -> long long {
+        int mm = m0 + MT * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        mm = mm < M ? mm : M - 1;
+        if constexpr (L == 3) return (long long)mm * 3136 + n;
+        else if constexpr (L == 2) return (long long)mm * 64 + n;
+        else {
+            const unsigned b = (unsigned)mm / 100u, p = (unsigned)mm - b * 100u, i2 = p / 10u, j2 = p - i2 * 10u;
+            return ((long long)(b * 20 + 2 * i2 + ph) * 20 + 2 * j2 + pw) * 32 + n;
+        }
+    };
+    TC gate_raw[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gate_raw[r] = act[out_off(r)];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
 #pragma unroll
@@ -408,20 +424,10 @@ k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, cons
             mfma_chunk<TC, MT>(lA + buf * (BM * LS) + (MT * wm + c) * LS, lB + buf * (BN * LS) + (MT * wn + c) * LS, hi, acc);
         }
     }
-    const int n = n0 + MT * wn + c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mm = m0 + MT * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (mm < M) {
-            long long o;
-            if constexpr (L == 3) o = (long long)mm * 3136 + n;
-            else if constexpr (L == 2) o = (long long)mm * 64 + n;
-            else {
-                const unsigned b = (unsigned)mm / 100u, p = (unsigned)mm - b * 100u, i2 = p / 10u, j2 = p - i2 * 10u;
-                o = ((long long)(b * 20 + 2 * i2 + ph) * 20 + 2 * j2 + pw) * 32 + n;
-            }
-            out[o] = (float)act[o] > 0.0f ? (TC)acc[r] : (TC)0.0f;
-        }
+        if (mm < M) out[out_off(r)] = (float)gate_raw[r] > 0.0f ? (TC)acc[r] : (TC)0.0f;
     }
 }
 

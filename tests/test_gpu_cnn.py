@@ -111,7 +111,7 @@ def grad_case(B, seed):
     return P, frames, targets, isw
 
 
-@pytest.mark.parametrize("B,use_isw", [(3, True), (16, False), (37, True)])
+@pytest.mark.parametrize("B,use_isw", [(1, False), (3, True), (16, False), (37, True)])
 def test_cnn_grads_f32(dq, B, use_isw):
     """jax.grad(compute_loss) through the CNN (exact-f32 mode) against the f64 form of the restatement: 1e-5 of every leaf's
     scale (the north_star's bar), loss 1e-6; ragged tiles, slices and parity classes (B = 3, 37)"""

@@ -5,10 +5,18 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/kt_$tag -- python3 $GRAFT_REPO_ROOT/tools/cnn_probe.py "$@" > $GRAFT_REPO_ROOT/gpurun_out/kt_$tag.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
+import subprocess
+_dem = {}
+def dem(n):      # rocprofv3 leaves names with the bf16 type (DF16b) mangled: demangle them as `half`, then rename
+    if not n.startswith("_Z"): return n
+    if n not in _dem:
+        try: _dem[n] = subprocess.run(["c++filt", n.replace("DF16b", "Dh")], capture_output=True, text=True).stdout.strip().replace("half", "bf16") or n
+        except Exception: _dem[n] = n
+    return _dem[n]
 f = sorted(glob.glob("$GRAFT_REPO_ROOT/gpurun_out/kt_$tag/*/*kernel_trace.csv"))[-1]
 acc = collections.defaultdict(list); order = []
 for r in csv.DictReader(open(f)):
-    n = r["Kernel_Name"]
+    n = dem(r["Kernel_Name"])
     if "k_cnn" in n or "k_td" in n:
         n = re.sub(r"\(.*", "", n).replace("void ", "")[:60]
         if n not in acc: order.append(n)

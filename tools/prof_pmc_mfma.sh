@@ -9,11 +9,19 @@ timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAV
 echo "rc=$?"; tail -2 $out/pmcm_$tag.log
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, json, sys, collections
+import subprocess
+_dem = {}
+def dem(n):      # rocprofv3 leaves names with the bf16 type (DF16b) mangled: demangle them as `half`, then rename
+    if not n.startswith("_Z"): return n
+    if n not in _dem:
+        try: _dem[n] = subprocess.run(["c++filt", n.replace("DF16b", "Dh")], capture_output=True, text=True).stdout.strip().replace("half", "bf16") or n
+        except Exception: _dem[n] = n
+    return _dem[n]
 root, tag = sys.argv[1], sys.argv[2]
 files = glob.glob(f"{root}/pmcm_{tag}/*/*counter_collection.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in csv.DictReader(open(files[0])):
-    n = row["Kernel_Name"].split("(")[0].replace("void ", "")
+    n = dem(row["Kernel_Name"]).split("(")[0].replace("void ", "")
     if not n.startswith("k_"): continue
     acc[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
