@@ -1,0 +1,90 @@
+"""The reference's control loop (`Agent.training`, General/QLearning/q_agent.py:171-222) for BASELINE configs[4]'s shape: vector
+envs that emit stacks of four 84x84 u8 frames, the Nature-CNN dueling Q-net, prioritized replay. Host logic only -- every
+numerical step is a C-ABI call:
+
+  act              dqn_cnn_act            (CNN forward + epsilon-greedy, q_agent.py:137-141)
+  add              dqn_cnn_replay_add     (frame ring, replay_buffer.py:58-65)  +  dqn_replay_add on the index engine, whose
+                                          sum tree gives the new rows the running maximum priority
+  sample           dqn_per_sample         on the index engine (a dqn_handle of the same capacity: positions only)
+  update           dqn_cnn_update_replay  (gather, three forwards, TD rule, backward, AdamW; q_agent.py:146-169)
+  write-back       dqn_per_update_sorted  with |delta|
+
+The env is synthetic (there is no ALE here and no network): frames are uniform u8, rewards N(0,1), dones Bernoulli(p_done) --
+the shape of PongNoFrameskip-v4 after the usual wrappers, not its dynamics.
+"""
+from __future__ import annotations
+
+import torch
+
+from ...cnn import CnnEngine
+from ...engine import Engine, EngineConfig
+
+
+class CnnVectorAgent:
+    def __init__(self, n_envs=512, num_actions=6, capacity=1 << 14, batch_size=512, precision="bf16", gamma=0.99, epsilon=1.0,
+                 epsilon_decay_rate=0.999, min_epsilon=0.1, train_frequency=4, replace_frequency=250, per_beta=0.4, p_done=0.01,
+                 lr=1e-4, seed=0, device=None):
+        if capacity % n_envs:
+            raise ValueError("capacity must be a multiple of n_envs (whole vector steps per ring lap)")
+        self.n_envs, self.B, self.gamma, self.seed = int(n_envs), int(batch_size), float(gamma), int(seed)
+        self.epsilon, self.decay, self.min_eps = float(epsilon), float(epsilon_decay_rate), float(min_epsilon)
+        self.train_frequency, self.replace_frequency, self.per_beta, self.p_done = int(train_frequency), int(replace_frequency), float(per_beta), float(p_done)
+        self.cnn = CnnEngine(num_actions=num_actions, max_batch=max(n_envs, batch_size), precision=precision, device=device)
+        self.cnn.replay_init(capacity)
+        self.cnn.set_optimizer(lr=lr)
+        # the PER tree: a dqn_handle whose ring holds one dummy float per position
+        self.index = Engine(EngineConfig(obs_dim=8, hidden1=16, hidden2=16, num_actions=4, capacity=capacity, use_per=True,
+                                         max_batch=max(n_envs, batch_size), seed=seed), device=device)
+        dev = self.cnn.device
+        self.gen = torch.Generator(device=dev); self.gen.manual_seed(seed + 1)
+        self.frames = self._new_frames()
+        self._zeros = (torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.int32, device=dev),
+                       torch.zeros((n_envs,), device=dev), torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.uint8, device=dev))
+        self.td_abs = torch.empty((self.B,), dtype=torch.float32, device=dev)
+        self.env_steps = self.updates = 0
+        self.losses = []
+
+    def close(self):
+        self.cnn.close(); self.index.close()
+
+    def init_params(self, flat, target_flat=None):
+        self.cnn.set_params(flat); self.cnn.set_params(flat if target_flat is None else target_flat, target=True)
+
+    def _new_frames(self):
+        return torch.randint(0, 256, (self.n_envs, 84, 84, 4), dtype=torch.uint8, device=self.cnn.device, generator=self.gen)
+
+    def env_step(self):
+        """one vector env step: act, synthetic transition, both rings"""
+        n, dev = self.n_envs, self.cnn.device
+        a = self.cnn.act(self.frames, self.epsilon, self.seed, self.env_steps)
+        nxt = self._new_frames()
+        r = torch.randn((n,), device=dev, generator=self.gen)
+        d = (torch.rand((n,), device=dev, generator=self.gen) < self.p_done).float()
+        first = self.cnn.replay_add(self.frames, a, r, nxt, d)
+        assert first == (self.env_steps * n) % self.cnn.capacity, (first, self.env_steps)      # the two rings move in lockstep
+        self.index.replay_add(*self._zeros)
+        self.frames = nxt
+        self.env_steps += 1
+        self.epsilon = max(self.epsilon * self.decay, self.min_eps)
+
+    def update(self, want_loss=False):
+        (_, _, _, _, _), idx, isw = self.index.per_sample(self.B, self.per_beta, self.seed, self.updates)
+        loss = self.cnn.update_from_replay(idx, isw, self.gamma, td_abs_out=self.td_abs, want_loss=want_loss)
+        self.index.per_update_sorted(idx, self.td_abs)
+        self.updates += 1
+        if self.updates % self.replace_frequency == 0:
+            self.cnn.sync_target()                                          # q_agent.py:192-193
+        if want_loss:
+            self.losses.append(loss)
+        return loss
+
+    def training(self, n_updates, warmup_steps=None, want_loss=False):
+        """q_agent.py:174-187: act every step, one update per train_frequency steps once the ring holds a batch"""
+        warm = warmup_steps if warmup_steps is not None else (self.B + self.n_envs - 1) // self.n_envs
+        while self.env_steps < warm:
+            self.env_step()
+        for _ in range(n_updates):
+            for _ in range(self.train_frequency):
+                self.env_step()
+            self.update(want_loss)
+        return self.losses

@@ -93,6 +93,12 @@ SIGNATURES = {
     "dqn_cnn_train_step": [_P, _P, _P, _P, _I32, _P],
     "dqn_cnn_update": [_P, _P, _P, _P, _P, _P, _P, _F, _I32, _P, _P],
     "dqn_cnn_sync_target": [_P, _P],
+    "dqn_cnn_act": [_P, _P, _I32, _F, C.c_uint64, C.c_uint64, _P, _P],
+    "dqn_cnn_replay_init": [_P, _I64],
+    "dqn_cnn_replay_add": [_P, _P, _P, _P, _P, _P, _I32, C.POINTER(_I64), _P],
+    "dqn_cnn_replay_size_host": [_P, C.POINTER(_I64), C.POINTER(_I64)],
+    "dqn_cnn_replay_gather": [_P, _P, _I32, _P, _P, _P, _P, _P, _P],
+    "dqn_cnn_update_replay": [_P, _P, _P, _F, _I32, _P, _P, _P],
 }
 OTHER = {"dqn_last_error": ([], C.c_char_p), "dqn_abi_version": ([], C.c_int),
          "dqn_default_config": ([C.POINTER(DqnConfig)], None)}

@@ -125,3 +125,47 @@ class CnnEngine:
 
     def sync_target(self):
         L.check(self.lib.dqn_cnn_sync_target(self.h, self._s()))
+
+    # ---- acting and the frame replay ring (the loop of BASELINE configs[4])
+    def act(self, frames, epsilon, seed=0, ctr=0, out=None):
+        """Agent._policy (q_agent.py:137-141) with the CNN as the model: epsilon-greedy actions [n] (int32)"""
+        x = self._frames(frames)
+        a = out if out is not None else torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
+        L.check(self.lib.dqn_cnn_act(self.h, _ptr(x), x.shape[0], float(epsilon), int(seed), int(ctr), _ptr(a), self._s()))
+        return a
+
+    def replay_init(self, capacity):
+        """ReplayBuffer.__init__ (replay_buffer.py:20-34) for frame stacks"""
+        L.check(self.lib.dqn_cnn_replay_init(self.h, int(capacity)))
+        self.capacity = int(capacity)
+
+    def replay_add(self, s, a, r, s2, d):
+        """ReplayBuffer.add (replay_buffer.py:58-65) for n transitions; returns the ring position of the first"""
+        s, s2 = self._frames(s), self._frames(s2)
+        a, r, d = self._t(a, torch.int32), self._t(r, torch.float32), self._t(d, torch.float32)
+        first = C.c_int64(0)
+        L.check(self.lib.dqn_cnn_replay_add(self.h, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), s.shape[0], C.byref(first), self._s()))
+        return first.value
+
+    def replay_size(self):
+        size, ctr = C.c_int64(), C.c_int64()
+        L.check(self.lib.dqn_cnn_replay_size_host(self.h, C.byref(size), C.byref(ctr)))
+        return size.value, ctr.value
+
+    def replay_gather(self, idx):
+        """the rows idx of the ring: (s, a, r, s2, d)"""
+        idx = self._t(idx, torch.int32); B = idx.numel()
+        s = torch.empty((B, 84, 84, 4), dtype=torch.uint8, device=self.device); s2 = torch.empty_like(s)
+        a = torch.empty((B,), dtype=torch.int32, device=self.device)
+        r = torch.empty((B,), dtype=torch.float32, device=self.device); d = torch.empty_like(r)
+        L.check(self.lib.dqn_cnn_replay_gather(self.h, _ptr(idx), B, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), self._s()))
+        return s, a, r, s2, d
+
+    def update_from_replay(self, idx, isw=None, gamma=0.99, td_abs_out=None, want_loss=False):
+        """Agent._step (q_agent.py:146-169) on the ring rows idx; td_abs_out (float32 [B], optional) receives |delta|"""
+        idx = self._t(idx, torch.int32)
+        w = None if isw is None else self._t(isw, torch.float32)
+        loss = C.c_float(0)
+        L.check(self.lib.dqn_cnn_update_replay(self.h, _ptr(idx), _ptr(w) if w is not None else None, float(gamma), idx.numel(),
+                                               _ptr(td_abs_out) if td_abs_out is not None else None, C.byref(loss) if want_loss else None, self._s()))
+        return loss.value if want_loss else None

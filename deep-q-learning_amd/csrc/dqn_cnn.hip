@@ -794,6 +794,33 @@ k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, flo
     scatter_shadows<TC>(o, sh, i, p);
 }
 
+// ------------------------------------------------------------------------------------ frame replay ring (configs[4] loop)
+// ReplayBuffer (General/Base/replay_buffer.py:20-85) for u8 frame stacks: rows of 84*84*4 = 28 224 bytes for s and for s'
+// (the reference stores both, :28-31), actions i32, rewards f32, dones f32. add = contiguous copies at the ring head (:58-65);
+// the sampled indices come from a PER tree kept by a dqn_handle of the same capacity (host mirror: CnnVectorAgent).
+constexpr int CNN_FRAME_BYTES = 84 * 84 * 4;
+// one workgroup per (sample, s | s'): 1764 16-byte pieces of a row; the scalars ride along in the first workgroups
+__global__ void __launch_bounds__(256)
+k_cnn_gather(const uint8_t *__restrict__ ring_s, const uint8_t *__restrict__ ring_s2, const int32_t *__restrict__ ring_a, const float *__restrict__ ring_r,
+             const float *__restrict__ ring_d, const int32_t *__restrict__ idx, int B, long long cap, uint8_t *__restrict__ s, uint8_t *__restrict__ s2,
+             int32_t *__restrict__ a, float *__restrict__ r, float *__restrict__ d) {
+    const int i = blockIdx.x, part = blockIdx.y;
+    long long row = idx[i];
+    row = row < 0 ? 0 : (row >= cap ? cap - 1 : row);
+    const uint4 *src = reinterpret_cast<const uint4 *>((part ? ring_s2 : ring_s) + row * CNN_FRAME_BYTES);
+    uint4 *dst = reinterpret_cast<uint4 *>((part ? s2 : s) + (long long)i * CNN_FRAME_BYTES);
+    uint4 v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { const int p = threadIdx.x + 256 * u; if (p < CNN_FRAME_BYTES / 16) v[u] = src[p]; }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { const int p = threadIdx.x + 256 * u; if (p < CNN_FRAME_BYTES / 16) dst[p] = v[u]; }
+    if (part == 0 && threadIdx.x == 0) { a[i] = ring_a[row]; r[i] = ring_r[row]; d[i] = ring_d[row]; }
+}
+__global__ void __launch_bounds__(256) k_cnn_abs(const float *__restrict__ x, int n, float *__restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = fabsf(x[i]);
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 #define CNN_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return dqn_set_error(DQN_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); } while (0)
 #define CNN_REQ(cond, msg) do { if (!(cond)) return dqn_set_error(DQN_ERR_INVALID, msg); } while (0)
@@ -814,6 +841,10 @@ struct dqn_cnn_handle {
     float *grad = nullptr, *mu = nullptr, *nu = nullptr, *loss_part = nullptr, *loss = nullptr, *targets = nullptr;
     float *slab[4] = {nullptr}, *bslab[4] = {nullptr}, *hslab = nullptr, *hbslab = nullptr; int smax[4] = {1, 1, 1, 1};
     CnnOptState *opt = nullptr;
+    // frame replay ring (dqn_cnn_replay_init)
+    void *ring_arena = nullptr; long long ring_cap = 0, ring_counter = 0;
+    uint8_t *ring_s = nullptr, *ring_s2 = nullptr, *stage_s = nullptr, *stage_s2 = nullptr; int32_t *ring_a = nullptr, *stage_a = nullptr;
+    float *ring_r = nullptr, *ring_d = nullptr, *stage_r = nullptr, *stage_d = nullptr, *td = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
 };
@@ -875,7 +906,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
     }
     const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
-    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 3 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
+    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
     for (int l = 0; l < 4; ++l) total += 2 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
@@ -891,6 +922,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     for (int i = 0; i < 3; ++i) h->q[i] = (float *)take(sz_q);
     h->targets = (float *)take(sz_q);
     h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
+    h->td = (float *)take(al((size_t)max_batch * 4));
     h->loss = (float *)take(256); h->opt = (CnnOptState *)take(256);
     h->hslab = (float *)take(sz_hslab); h->hbslab = (float *)take(sz_hbslab);
     (void)hipMemset(h->arena, 0, total);
@@ -912,6 +944,7 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->arena) (void)hipFree(h->arena);
+    if (h->ring_arena) (void)hipFree(h->ring_arena);
     delete h;
     return DQN_OK;
 }
@@ -1125,14 +1158,98 @@ extern "C" int dqn_cnn_train_step(dqn_cnn_handle *h, const uint8_t *frames, cons
 
 /* Agent._step (q_agent.py:146-169) on a given minibatch: compute_q_targets (three forwards), then train_step's backward from
  * the activations of the online pass over s (the fourth forward of the reference's two separate jits is the same numbers),
- * Adam / AdamW. loss_host optional. */
-extern "C" int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
-                              const float *isw, float gamma, int32_t B, float *loss_host, void *stream) {
-    int rc = dqn_cnn_q_targets(h, s, a, r, s2, d, gamma, B, h->targets, stream); if (rc) return rc;
+ * Adam / AdamW. loss_host optional; td_abs_out (device, B floats, optional) = |delta| of q_learning_functions.py:58 per sample
+ * (the priorities a PER write-back wants). */
+static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
+                           const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream) {
+    CNN_REQ(h && s && a && r && s2 && d, "null argument");
+    CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
+    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s2, B, h->q[1], stream); if (rc) return rc;          // :53
+    rc = dqn_cnn_forward(h, DQN_NET_TARGET, s2, B, h->q[2], stream); if (rc) return rc;              // :54
+    rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s, B, h->q[0], stream); if (rc) return rc;               // :52
+    launch_td(st, h->q[0], h->q[1], h->q[2], a, r, d, nullptr, gamma, B, h->A, h->targets, td_abs_out ? h->td : nullptr, nullptr, nullptr, h->scratch);
+    if (td_abs_out) hipLaunchKernelGGL(k_cnn_abs, dim3((B + 255) / 256), dim3(256), 0, st, h->td, B, td_abs_out);
     if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
     CNN_TRY(hipGetLastError());
     rc = cnn_adam(h, 1.0f, st); if (rc) return rc;
     if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
     return DQN_OK;
+}
+extern "C" int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
+                              const float *isw, float gamma, int32_t B, float *loss_host, void *stream) {
+    return cnn_update_impl(h, s, a, r, s2, d, isw, gamma, B, nullptr, loss_host, stream);
+}
+
+/* Agent._policy (q_agent.py:137-141) with the CNN: epsilon-greedy actions for n frame stacks; Philox (seed, ctr, i, policy
+ * stream) as dqn_act */
+extern "C" int dqn_cnn_act(dqn_cnn_handle *h, const uint8_t *frames, int32_t n, float epsilon, uint64_t seed, uint64_t ctr, int32_t *actions, void *stream) {
+    CNN_REQ(h && frames && actions, "null argument");
+    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, frames, n, h->q[0], stream); if (rc) return rc;
+    launch_policy((hipStream_t)stream, h->q[0], n, h->A, epsilon, seed, ctr, actions, nullptr);
+    CNN_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+/* ReplayBuffer.__init__ (replay_buffer.py:20-34) for frame stacks: capacity rows of s, s' (u8), a, r, d; zeroed */
+extern "C" int dqn_cnn_replay_init(dqn_cnn_handle *h, int64_t capacity) {
+    CNN_REQ(h && capacity >= 1 && capacity <= ((int64_t)1 << 24), "dqn_cnn_replay_init: bad capacity");
+    CNN_REQ(!h->ring_arena, "the ring exists already");
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t fr = al((size_t)capacity * CNN_FRAME_BYTES), sc = al((size_t)capacity * 4), sfr = al((size_t)h->max_batch * CNN_FRAME_BYTES), ssc = al((size_t)h->max_batch * 4);
+    const size_t total = 2 * fr + 3 * sc + 2 * sfr + 3 * ssc;
+    hipError_t e = hipMalloc(&h->ring_arena, total);
+    if (e != hipSuccess) { h->ring_arena = nullptr; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc (frame ring): ") + hipGetErrorString(e)).c_str()); }
+    char *c = (char *)h->ring_arena;
+    h->ring_s = (uint8_t *)c; c += fr; h->ring_s2 = (uint8_t *)c; c += fr;
+    h->ring_a = (int32_t *)c; c += sc; h->ring_r = (float *)c; c += sc; h->ring_d = (float *)c; c += sc;
+    h->stage_s = (uint8_t *)c; c += sfr; h->stage_s2 = (uint8_t *)c; c += sfr;
+    h->stage_a = (int32_t *)c; c += ssc; h->stage_r = (float *)c; c += ssc; h->stage_d = (float *)c; c += ssc;
+    CNN_TRY(hipMemset(h->ring_arena, 0, total));
+    h->ring_cap = capacity; h->ring_counter = 0;
+    return DQN_OK;
+}
+
+/* ReplayBuffer.add (replay_buffer.py:58-65), n transitions at once: rows counter .. counter + n - 1 (mod capacity).
+ * first_index (optional) receives the ring position of the first one. */
+extern "C" int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
+                                  int32_t n, int64_t *first_index, void *stream) {
+    CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
+    CNN_REQ(s && a && r && s2 && d && n >= 1 && n <= h->ring_cap, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long long pos = h->ring_counter % h->ring_cap, n1 = (pos + n <= h->ring_cap) ? n : h->ring_cap - pos, n2 = n - n1;
+    auto put = [&](void *ring, const void *src, size_t row) -> hipError_t {
+        hipError_t e = hipMemcpyAsync((char *)ring + pos * row, src, n1 * row, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && n2) e = hipMemcpyAsync(ring, (const char *)src + n1 * row, n2 * row, hipMemcpyDeviceToDevice, st);
+        return e;
+    };
+    CNN_TRY(put(h->ring_s, s, CNN_FRAME_BYTES)); CNN_TRY(put(h->ring_s2, s2, CNN_FRAME_BYTES));
+    CNN_TRY(put(h->ring_a, a, 4)); CNN_TRY(put(h->ring_r, r, 4)); CNN_TRY(put(h->ring_d, d, 4));
+    if (first_index) *first_index = pos;
+    h->ring_counter += n;
+    return DQN_OK;
+}
+
+extern "C" int dqn_cnn_replay_size_host(const dqn_cnn_handle *h, int64_t *size, int64_t *counter) {
+    CNN_REQ(h && size && counter, "null argument");
+    *counter = h->ring_counter; *size = h->ring_counter < h->ring_cap ? h->ring_counter : h->ring_cap;
+    return DQN_OK;
+}
+
+/* sample_batch's gather (replay_buffer.py:79-85) for given indices */
+extern "C" int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, uint8_t *s, int32_t *a, float *r, uint8_t *s2, float *d, void *stream) {
+    CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
+    CNN_REQ(idx && s && a && r && s2 && d && B >= 1, "bad argument");
+    hipLaunchKernelGGL(k_cnn_gather, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, h->ring_s, h->ring_s2, h->ring_a, h->ring_r, h->ring_d, idx, B, h->ring_cap, s, s2, a, r, d);
+    CNN_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
+/* Agent._step (q_agent.py:146-169) from the frame ring: gather the rows idx (sampled by the caller's PER tree), update with
+ * the importance weights isw (optional), |delta| per sample into td_abs_out (optional) for the priority write-back */
+extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream) {
+    CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
+    CNN_REQ(idx && B >= 1 && B <= h->max_batch, "bad argument");
+    int rc = dqn_cnn_replay_gather(h, idx, B, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
+    return cnn_update_impl(h, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, isw, gamma, B, td_abs_out, loss_host, stream);
 }

@@ -275,6 +275,21 @@ int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const 
                    const float *isw, float gamma, int32_t B, float *loss_host, void *stream);
 /* Agent._update_target_model (q_agent.py:143-144) */
 int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream);
+/* Agent._policy (q_agent.py:137-141) with the CNN as the model: epsilon-greedy actions for n frame stacks (Philox as dqn_act) */
+int dqn_cnn_act(dqn_cnn_handle *h, const uint8_t *frames, int32_t n, float epsilon, uint64_t seed, uint64_t ctr,
+                int32_t *actions, void *stream);
+/* ReplayBuffer (General/Base/replay_buffer.py:20-85) for u8 frame stacks inside the CNN handle: init (zeroed ring of s, s', a,
+ * r, d), add n transitions at the head, gather given rows; the PER tree over the same positions is a dqn_handle of the same
+ * capacity (its dqn_per_sample / dqn_per_update_sorted give and take the indices). d is f32 (preprocessing :84). */
+int dqn_cnn_replay_init(dqn_cnn_handle *h, int64_t capacity);
+int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
+                       const float *d, int32_t n, int64_t *first_index, void *stream);
+int dqn_cnn_replay_size_host(const dqn_cnn_handle *h, int64_t *size, int64_t *counter);
+int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, uint8_t *s, int32_t *a, float *r, uint8_t *s2,
+                          float *d, void *stream);
+/* Agent._step from the frame ring: gather idx + dqn_cnn_update; td_abs_out (device, optional) = |delta| per sample */
+int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t B,
+                          float *td_abs_out, float *loss_host, void *stream);
 
 #ifdef __cplusplus
 }

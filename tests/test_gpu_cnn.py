@@ -235,3 +235,90 @@ def test_cnn_data_parallel_halves(dq):
     assert moved.mean() > 0.3 and np.mean(np.abs(pa - pf) > 2e-5) < 1e-3        # (inputs that are 0 for all 16 samples leave their fc rows untouched)
     for e in (full, a, b):
         e.close()
+
+
+def test_cnn_frame_ring_and_gather(dq):
+    """ReplayBuffer.add / the gather of sample_batch (replay_buffer.py:58-65, :79-85) for frame stacks: rows land at
+    counter % capacity incl. the wrap, gathered rows are the bytes that were added (duplicates and the last row included)"""
+    import torch
+    cap, n = 24, 10
+    e = dq.CnnEngine(num_actions=A, max_batch=16, precision="bf16")
+    e.replay_init(cap)
+    rng = np.random.default_rng(3)
+    ring = {k: None for k in "s a r s2 d".split()}
+    model_s = np.zeros((cap, 84, 84, 4), np.uint8); model_s2 = np.zeros_like(model_s)
+    model_a = np.zeros(cap, np.int32); model_r = np.zeros(cap, np.float32); model_d = np.zeros(cap, np.float32)
+    ctr = 0
+    for step in range(4):                                               # 40 rows into 24: wraps in the third add
+        s = rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8); s2 = rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8)
+        a = rng.integers(0, A, n).astype(np.int32); r = rng.standard_normal(n).astype(np.float32); d = (rng.random(n) < 0.3).astype(np.float32)
+        first = e.replay_add(s, a, r, s2, d)
+        assert first == ctr % cap
+        pos = (ctr + np.arange(n)) % cap
+        model_s[pos], model_s2[pos], model_a[pos], model_r[pos], model_d[pos] = s, s2, a, r, d
+        ctr += n
+        assert e.replay_size() == (min(ctr, cap), ctr)
+    idx = np.array([0, 0, 5, 9, 10, 17, 23, 23, 3], np.int32)
+    gs, ga, gr, gs2, gd = (host(t) for t in e.replay_gather(idx))
+    assert np.array_equal(gs, model_s[idx]) and np.array_equal(gs2, model_s2[idx])
+    assert np.array_equal(ga, model_a[idx]) and np.array_equal(gr, model_r[idx]) and np.array_equal(gd, model_d[idx])
+    # update_from_replay == update on the gathered rows (same handle state: two handles, same parameters)
+    e2 = dq.CnnEngine(num_actions=A, max_batch=16, precision="bf16")
+    P = make_params(4)
+    for x in (e, e2):
+        x.set_params(P); x.set_params(P, target=True); x.set_optimizer(lr=1e-3)
+    isw = rng.uniform(0.3, 1.0, idx.size).astype(np.float32)
+    td = torch.empty(idx.size, dtype=torch.float32, device="cuda")
+    l1 = e.update_from_replay(idx, isw, 0.99, td_abs_out=td, want_loss=True)
+    l2 = e2.update(gs, ga, gr, gs2, gd, isw, 0.99, want_loss=True)
+    assert l1 == l2 and np.array_equal(host(e.get_buffer("params")), host(e2.get_buffer("params")))
+    # |delta| of q_learning_functions.py:58 on the bf16 forward's own Q values
+    e3 = dq.CnnEngine(num_actions=A, max_batch=16, precision="bf16"); e3.set_params(P); e3.set_params(P, target=True)
+    q, nq, nt = host(e3.forward(gs)), host(e3.forward(gs2)), host(e3.forward(gs2, target=True))
+    i = np.arange(idx.size)
+    delta = gr + (np.float32(1.0) - gd) * (np.float32(0.99) * nt[i, nq.argmax(1)] - q[i, ga])
+    assert np.array_equal(host(td), np.abs(delta))
+    for x in (e, e2, e3):
+        x.close()
+
+
+def test_cnn_act(dq):
+    """Agent._policy (q_agent.py:137-141) with the CNN: epsilon = 0 -> argmax of the CNN's Q (first maximum); epsilon = 1 -> the
+    same Philox draws as dqn_act of the MLP engine (policy stream, (seed, ctr, i)); repeatable"""
+    n = 40
+    e = dq.CnnEngine(num_actions=4, max_batch=64, precision="f32")
+    rng = np.random.default_rng(9)
+    P = onp.cnn_init_params(4, 9); P = (P + 0.01 * rng.standard_normal(P.size)).astype(np.float32)
+    e.set_params(P)
+    frames = rng.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8)
+    q, _ = oc.cnn_forward(P, frames, 4)
+    assert np.array_equal(host(e.act(frames, 0.0, 5, 7)), q.argmax(1).astype(np.int32))
+    a1 = host(e.act(frames, 1.0, 5, 7))
+    assert np.array_equal(a1, host(e.act(frames, 1.0, 5, 7))) and not np.array_equal(a1, host(e.act(frames, 1.0, 5, 8)))
+    m = dq.Engine(dq.EngineConfig(obs_dim=8, hidden1=16, hidden2=16, num_actions=4, capacity=64, use_per=False, max_batch=64, seed=1))
+    am = host(m.act(np.zeros((n, 8), np.float32), 1.0, 5, 7))
+    assert np.array_equal(a1, am) and set(a1) == {0, 1, 2, 3}
+    half = host(e.act(frames, 0.5, 5, 7))
+    greedy = q.argmax(1)
+    assert 0.2 < np.mean(half == greedy) < 1.0 and np.mean(half != greedy) > 0.1
+    e.close(); m.close()
+
+
+def test_cnn_vector_agent_loop(dq):
+    """the loop of BASELINE configs[4]'s shape (synthetic frames): act -> add to both rings -> PER sample -> update from the frame
+    ring -> priority write-back. Checks the plumbing: ring counters in lockstep, priorities of sampled rows move off the
+    initial maximum, parameters move, losses finite, no device error."""
+    from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
+    ag = CnnVectorAgent(n_envs=16, num_actions=A, capacity=64, batch_size=32, precision="bf16", train_frequency=2, replace_frequency=2, lr=1e-3, seed=3)
+    P = make_params(12)
+    ag.init_params(P)
+    losses = ag.training(3, want_loss=True)
+    assert len(losses) == 3 and all(np.isfinite(l) and l > 0 for l in losses)
+    assert ag.env_steps == 2 + 3 * 2 and ag.updates == 3
+    assert ag.cnn.replay_size() == (64, ag.env_steps * 16) and ag.index.replay_size() == (64, ag.env_steps * 16)
+    assert np.abs(host(ag.cnn.get_buffer("params")) - P).max() > 0
+    tree = host(ag.index.buffer(dq._lib.BUF_TREE))
+    leaves = tree[64:128]
+    assert leaves.min() > 0 and len(np.unique(leaves)) > 8            # written-back |delta|^alpha next to max-priority new rows
+    assert ag.index.device_errors() == 0
+    ag.close()
