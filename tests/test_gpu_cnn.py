@@ -322,3 +322,30 @@ def test_cnn_vector_agent_loop(dq):
     assert leaves.min() > 0 and len(np.unique(leaves)) > 8            # written-back |delta|^alpha next to max-priority new rows
     assert ag.index.device_errors() == 0
     ag.close()
+
+
+def test_cnn_against_golden(dq):
+    """the HIP path against the committed vector tests/golden/cnn_B4_seed7.npz (no restatement in the loop): exact-f32 forward
+    bit-identical to the stored f32 Q and within 1e-5 of the stored f64 Q, loss and per-leaf gradient sums / samples within 1e-5
+    of the leaf scale"""
+    import os, sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import make_cnn_golden as mk
+    g = np.load(os.path.join(gold, "cnn_B4_seed7.npz"))
+    P, frames, noise, scale, isw = mk.inputs(int(g["seed"]), int(g["B"]))
+    e = dq.CnnEngine(num_actions=int(g["A"]), max_batch=8, precision="f32")
+    e.set_params(P)
+    q = host(e.forward(frames))
+    assert np.array_equal(q, g["q32"]) and np.allclose(q, g["q64"], rtol=1e-5, atol=1e-5)
+    loss = e.grads(frames, g["targets"], isw)
+    assert abs(loss - float(g["loss64"])) <= 1e-6 * max(1.0, float(g["loss64"]))
+    gr = host(e.get_buffer("grad")).astype(np.float64)
+    o = 0
+    for n, s_, a_ in zip(mk.LEAVES, g["leaf_sums"], g["leaf_abs"]):
+        leaf = gr[o:o + n]
+        assert abs(np.abs(leaf).sum() - a_) <= 1e-5 * a_ and abs(leaf.sum() - s_) <= 1e-5 * a_
+        o += n
+    ref = g["grad64_strided"]
+    assert np.abs(gr[::997] - ref).max() <= 1e-5 * np.abs(ref).max()
+    e.close()

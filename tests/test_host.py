@@ -245,3 +245,27 @@ def test_data_parallel_recipe_gloo_world2():
             gs.append(onp.grads(Pw, s, tg, dims, None, np.float64)[0])
         Pw, mu, nu, cnt = onp.adam_step(Pw, gs[0] + gs[1], mu, nu, cnt, 2e-4, dtype=np.float64, grad_scale=0.5)
     assert np.allclose(res[0][1], Pw, rtol=0, atol=1e-12)
+
+
+def test_cnn_oracle_reproduces_golden():
+    """the Nature-CNN restatement (forward f32 / f64, loss gradient f32 / f64) against the committed vector
+    tests/golden/cnn_B4_seed7.npz (regression pin; inputs re-generated from the recorded seeds and checked by their sums)"""
+    sys.path.insert(0, GOLD)
+    import make_cnn_golden as mk
+    g = np.load(os.path.join(GOLD, "cnn_B4_seed7.npz"))
+    A = int(g["A"])
+    P, frames, noise, scale, isw = mk.inputs(int(g["seed"]), int(g["B"]))
+    assert P.astype(np.float64).sum() == float(g["param_sum"]) and int(frames.astype(np.int64).sum()) == int(g["frame_sum"])
+    q32, feat = oc.cnn_forward(P, frames, A)
+    assert np.array_equal(q32, g["q32"]) and feat.astype(np.float64).sum() == float(g["feat32_sum"])
+    assert np.allclose(onp.cnn_forward(P, frames, A, np.float64), g["q64"], rtol=1e-12, atol=1e-12)
+    targets = (q32 + noise * scale).astype(np.float32)
+    assert np.array_equal(targets, g["targets"])
+    g64, l64 = oc.cnn_grads(P, frames, targets, isw, A, f64=True)
+    g32, l32 = oc.cnn_grads(P, frames, targets, isw, A)
+    assert abs(l64 - float(g["loss64"])) <= 1e-12 and np.float32(l32) == g["loss32"]
+    assert np.allclose(g64[::997], g["grad64_strided"], rtol=1e-10, atol=1e-14) and np.array_equal(g32[::997], g["grad32_strided"])
+    o = 0
+    for n, s_, a_ in zip(mk.LEAVES, g["leaf_sums"], g["leaf_abs"]):
+        assert np.isclose(g64[o:o + n].sum(), s_, rtol=1e-9, atol=1e-13) and np.isclose(np.abs(g64[o:o + n]).sum(), a_, rtol=1e-10)
+        o += n
