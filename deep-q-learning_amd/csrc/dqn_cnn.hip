@@ -116,7 +116,8 @@ __device__ __forceinline__ void commit_piece(float *row, int j, const TR &raw, c
 // neighbours in m (shared patch rows / weight columns stay in that XCD's L2).
 template <typename TI, typename TC, int L, int V>
 __global__ void __launch_bounds__(256)
-k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out) {
+k_cnn_layer(int M, const TI *__restrict__ in, const TI *__restrict__ in2, int images1, const TC *__restrict__ wt, const float *__restrict__ bias, TC *__restrict__ out) {
+    // images 0 .. images1-1 come from `in`, the rest from `in2` (two frame batches through one pass; layers above conv1: one tensor)
     typedef CnnGeo<L> G; typedef CnnTile<L, V> T;
     constexpr int MT = T::MT, WM = T::WM, WN = T::WN, TM = T::TM, TN = T::TN, R = T::R;
     constexpr int BM = MT * WM * TM, BN = MT * WN * TN, K = G::KH * G::KW * G::IC, ROWLEN = G::KW * G::IC, NCH = K / KC;
@@ -143,7 +144,8 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TC *__restrict__ wt, const f
         int mm = m0 + (tid >> 3) + 32 * u;
         mm = mm < M ? mm : M - 1;                                                      // rows past the end: a valid row, never stored
         const unsigned ow = (unsigned)mm % G::OW, t2 = (unsigned)mm / G::OW, oh = t2 % G::OH, b = t2 / G::OH;
-        ap[u] = in + ((long long)(b * G::IH + oh * G::S) * G::IW + ow * G::S) * G::IC;
+        const bool second = (int)b >= images1;
+        ap[u] = (second ? in2 : in) + ((long long)((second ? b - images1 : b) * G::IH + oh * G::S) * G::IW + ow * G::S) * G::IC;
     }
 #pragma unroll
     for (int u = 0; u < BPT; ++u) bp[u] = wt + (long long)(n0 + (tid >> 3) + 32 * u) * K + 8 * pj;
@@ -902,12 +904,12 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     size_t sz_wt[4], sz_act[4], sz_slab[4], sz_bslab[4];
     for (int l = 0; l < 4; ++l) {
         sz_wt[l] = al((size_t)h->L[l].K * h->L[l].N * esz);
-        sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz);
+        sz_act[l] = al((size_t)max_batch * cnn_shape(l).positions * h->L[l].N * esz);          // activations hold 2 x this (the paired pass), gradients 1 x
         sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
     }
     const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
-    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 5 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
-    for (int l = 0; l < 4; ++l) total += 2 * sz_act[l] + sz_slab[l] + sz_bslab[l];
+    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 6 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
+    for (int l = 0; l < 4; ++l) total += 3 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
     char *c = (char *)h->arena;
@@ -918,8 +920,8 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh);
     }
     h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
-    for (int l = 0; l < 4; ++l) { h->act[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
-    for (int i = 0; i < 3; ++i) h->q[i] = (float *)take(sz_q);
+    for (int l = 0; l < 4; ++l) { h->act[l] = take(2 * sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
+    h->q[0] = (float *)take(2 * sz_q); h->q[1] = nullptr; h->q[2] = (float *)take(sz_q);      // q[0]: [2 B][A] of the paired online pass
     h->targets = (float *)take(sz_q);
     h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
     h->td = (float *)take(al((size_t)max_batch * 4));
@@ -1004,57 +1006,60 @@ extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
 }
 
 template <typename TI, typename TC, int L>
-static void launch_layer(hipStream_t s, int B, const TI *in, const TC *wt, const float *bias, TC *out) {
+static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int images1, const TC *wt, const float *bias, TC *out) {
     typedef CnnGeo<L> G;
     const int M = B * G::OH * G::OW;
     if constexpr (sizeof(TC) == 2 && L == 3) {
         if (B >= 8192) {
             typedef CnnTile<L, 1> T;
             const int BM = T::MT * T::WM * T::TM, BN = T::MT * T::WN * T::TN;
-            DQN_LAUNCH((k_cnn_layer<TI, TC, L, 1>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
+            DQN_LAUNCH((k_cnn_layer<TI, TC, L, 1>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, in2, images1, wt, bias, out);
             return;
         }
     }
     {
         typedef CnnTile<L, 0> T;
         const int BM = T::MT * T::WM * T::TM, BN = T::MT * T::WN * T::TN;
-        DQN_LAUNCH((k_cnn_layer<TI, TC, L, 0>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, wt, bias, out);
+        DQN_LAUNCH((k_cnn_layer<TI, TC, L, 0>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, in2, images1, wt, bias, out);
     }
 }
 
+// one pass over B1 frame stacks from `frames` followed by B2 from `frames2` (B2 = 0: a plain forward); q: [B1 + B2][A]
 template <typename TC>
-static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B, float *q, hipStream_t s) {
+static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s) {
     const float *P = h->params[which];
+    const int B = B1 + B2;
     TC *a0 = (TC *)h->act[0], *a1 = (TC *)h->act[1], *a2 = (TC *)h->act[2], *a3 = (TC *)h->act[3];
-    launch_layer<uint8_t, TC, 0>(s, B, frames, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
-    launch_layer<TC, TC, 1>(s, B, a0, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
-    launch_layer<TC, TC, 2>(s, B, a1, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
-    launch_layer<TC, TC, 3>(s, B, a2, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3);
+    launch_layer<uint8_t, TC, 0>(s, B, frames, frames2 ? frames2 : frames, B1, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
+    launch_layer<TC, TC, 1>(s, B, a0, a0, B, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
+    launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
+    launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3);
     hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
+}
+static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s) {
+    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
 extern "C" int dqn_cnn_forward(dqn_cnn_handle *h, int which, const uint8_t *frames, int32_t B, float *q, void *stream) {
     CNN_REQ(h && frames && q && (which == DQN_NET_ONLINE || which == DQN_NET_TARGET), "bad argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
-    if (h->bf16) cnn_forward_t<__bf16>(h, which, frames, B, q, (hipStream_t)stream);
-    else cnn_forward_t<float>(h, which, frames, B, q, (hipStream_t)stream);
+    cnn_forward_pair(h, which, frames, B, nullptr, 0, q, (hipStream_t)stream);
     CNN_TRY(hipGetLastError());
     return DQN_OK;
 }
 
 /* compute_q_targets (q_learning_functions.py:42-64) with the CNN as the model: three forwards + the TD rule (k_td).
- * targets: [B][A] (the predictions with the taken action's entry replaced, :61-63). The online pass over s runs last, so its
- * activations are the ones left in the handle (dqn_cnn_update continues with the backward from them). */
+ * targets: [B][A] (the predictions with the taken action's entry replaced, :61-63). The target pass runs first; the two online
+ * passes (s, s') are ONE pass over 2 B frame stacks, s first, so its activations are the ones the backward finds at rows [0, B). */
 extern "C" int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
                                  const float *d, float gamma, int32_t B, float *targets, void *stream) {
     CNN_REQ(h && s && a && r && s2 && d && targets, "null argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
-    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s2, B, h->q[1], stream); if (rc) return rc;          // :53
-    rc = dqn_cnn_forward(h, DQN_NET_TARGET, s2, B, h->q[2], stream); if (rc) return rc;              // :54
-    rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s, B, h->q[0], stream); if (rc) return rc;               // :52
-    launch_td(st, h->q[0], h->q[1], h->q[2], a, r, d, nullptr, gamma, B, h->A, targets, nullptr, nullptr, nullptr, h->scratch);
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], st);                             // :54
+    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // :52, :53 in one pass: q rows [0, B) | [B, 2B)
+    launch_td(st, h->q[0], h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, nullptr, gamma, B, h->A, targets, nullptr, nullptr, nullptr, h->scratch);
     CNN_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -1165,10 +1170,10 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     CNN_REQ(h && s && a && r && s2 && d, "null argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
-    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s2, B, h->q[1], stream); if (rc) return rc;          // :53
-    rc = dqn_cnn_forward(h, DQN_NET_TARGET, s2, B, h->q[2], stream); if (rc) return rc;              // :54
-    rc = dqn_cnn_forward(h, DQN_NET_ONLINE, s, B, h->q[0], stream); if (rc) return rc;               // :52
-    launch_td(st, h->q[0], h->q[1], h->q[2], a, r, d, nullptr, gamma, B, h->A, h->targets, td_abs_out ? h->td : nullptr, nullptr, nullptr, h->scratch);
+    int rc = DQN_OK;
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], st);                             // :54
+    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // :52, :53 in one pass; s's activations are rows [0, B)
+    launch_td(st, h->q[0], h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, nullptr, gamma, B, h->A, h->targets, td_abs_out ? h->td : nullptr, nullptr, nullptr, h->scratch);
     if (td_abs_out) hipLaunchKernelGGL(k_cnn_abs, dim3((B + 255) / 256), dim3(256), 0, st, h->td, B, td_abs_out);
     if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
     CNN_TRY(hipGetLastError());
