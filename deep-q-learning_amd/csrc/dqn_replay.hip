@@ -112,14 +112,18 @@ k_sample_uniform(const DqnState *st, const float *states, const int32_t *actions
 // One wave = one 64-sample chunk at a time; a workgroup walks a contiguous range of chunks (persistent grid).
 // ctr_from_state: take the Philox counter / beta from the device state (graph replay) and publish the batch max there.
 #ifndef PS_BAND
-#define PS_BAND 1024         // floats of LDS per wave for a band
+#define PS_BAND 512          // floats of LDS per wave for a band
 #endif
 #define PS_WIDE 256          // run width beyond which a band costs more bytes than per-lane loads
 #ifndef PS_TOPL
-#define PS_TOPL 13           // deepest level walked in the shared LDS image (64 KiB)
+#define PS_TOPL 12           // deepest level walked in the shared LDS image (32 KiB)
 #endif
 #ifndef PS_WGS_PER_CU
-#define PS_WGS_PER_CU 1      // 16-wave workgroups per CU (LDS: 4 * 2^(PS_TOPL+1) + 64 * PS_BAND bytes each)
+#define PS_WGS_PER_CU 2      // 16-wave workgroups per CU (LDS: 4 * 2^(PS_TOPL+1) + 64 * PS_BAND bytes each)
+// r02 choice of the three: B = 2^20 runs in one of two placement modes. One workgroup per CU with a 64 KiB image
+// and 4 KiB bands (13 / 1024 / 1) is 34 us in the cache-resident mode and 54 us in the other; two workgroups per CU with half
+// the LDS each (12 / 512 / 2: 32 waves per CU in flight) is 39 us and 46 us -- above 60 % of the HBM peak in algorithmic bytes
+// in BOTH modes, which the first is not.
 #endif
 
 struct PerSampleArgs {

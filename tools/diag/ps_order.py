@@ -1,9 +1,11 @@
-"""per_sample_lines' body with the list of batch sizes as an argument:  python tools/diag/ps_order.py 10,16,18,20"""
+"""per_sample_lines' body with the list of batch sizes as an argument:  python tools/diag/ps_order.py 10,16,18,20 [variant.so]"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench, deep_q_learning_amd as dq
+if len(sys.argv) > 2:          # a variant build of the library (tools/diag/_var/*.so: other PS_* macros)
+    dq._lib.LIB_PATH = os.path.abspath(sys.argv[2])
 lbs = [int(x) for x in sys.argv[1].split(",")]
 eng = dq.Engine(dq.EngineConfig(obs_dim=8, hidden1=16, hidden2=16, num_actions=4, capacity=1 << 20, use_per=True, max_batch=1 << 20, seed=77))
 gen = torch.Generator(device=eng.device); gen.manual_seed(99)

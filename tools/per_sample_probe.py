@@ -24,7 +24,10 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--json", default=None)
     ap.add_argument("--plain", type=int, default=0)
+    ap.add_argument("--lib", default=None, help="a variant build of the library (other PS_* macros)")
     args = ap.parse_args()
+    if args.lib:
+        dq._lib.LIB_PATH = os.path.abspath(args.lib)
     D, L = bench.D, bench.LOG2N
     maxB = 1 << max(args.log2)
     eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=16, hidden2=16, num_actions=bench.A, capacity=1 << L, use_per=True,
