@@ -689,9 +689,10 @@ k_cnn_head_bwd(const float *__restrict__ q, const float *__restrict__ targets, c
 }
 
 // grad leaf = sum over the slices of its slab, in slice order (deterministic); loss = sum of the head partials / B.
-// A segment is walked four elements per thread where its size and offsets allow; adv > 0 marks the adv-head leaf, whose slab
-// is output-major ([1 + j][k]) while the leaf is [k][j].
-struct CnnSeg { const float *slab; long long n, dst, stride, units; int S, adv; float div; };
+// Where a segment's size and offsets allow, four elements are summed by 8 lanes (each an eighth of the slices, partials added in
+// lane order: 200 dependent slices of conv1's slab were 17 of the kernel's 21 us); adv > 0 marks the adv-head leaf, whose slab is
+// output-major ([1 + j][k]) while the leaf is [k][j]. units = threads of the segment (vector segments: 8 per float4).
+struct CnnSeg { const float *slab; long long n, dst, stride, units; int S, adv; float div; int vec; };      // units: multiples of 8 (whole lane groups)
 struct CnnSegs { CnnSeg s[12]; int count; };
 __global__ void __launch_bounds__(256)
 k_cnn_reduce(CnnSegs segs, long long total_units, float *__restrict__ grad, const float *__restrict__ loss_part, int loss_parts, int B, float *__restrict__ loss) {
@@ -701,23 +702,36 @@ k_cnn_reduce(CnnSegs segs, long long total_units, float *__restrict__ grad, cons
     int g = 0;
     for (int i = 0; i + 1 < segs.count; ++i) if (g == i && t >= segs.s[i].units) { t -= segs.s[i].units; ++g; }
     const CnnSeg sg = segs.s[g];
-    if (sg.units != sg.n) {                                          // four elements per thread
-        const float4 *p = reinterpret_cast<const float4 *>(sg.slab + 4 * t);
+    if (sg.vec) {                // four elements per 8 lanes: lane g sums its eighth of the slices (in order), the eight partials are added in lane order
+        const int g = (int)(t & 7);
+        const long long unit = t >> 3;
+        const float4 *p = reinterpret_cast<const float4 *>(sg.slab + 4 * unit);
         const long long st4 = sg.stride / 4;
+        const int per = (sg.S + 7) / 8, s0 = g * per, s1 = min(sg.S, s0 + per);
         float4 acc = float4{0.0f, 0.0f, 0.0f, 0.0f};
-        int s = 0;
-        for (; s + 8 <= sg.S; s += 8) {
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * st4];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { acc.x = acc.x + v[u].x; acc.y = acc.y + v[u].y; acc.z = acc.z + v[u].z; acc.w = acc.w + v[u].w; }
         }
-        for (; s < sg.S; ++s) { const float4 v = p[(long long)s * st4]; acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
-        if (sg.div != 1.0f) { acc.x = __fdiv_rn(acc.x, sg.div); acc.y = __fdiv_rn(acc.y, sg.div); acc.z = __fdiv_rn(acc.z, sg.div); acc.w = __fdiv_rn(acc.w, sg.div); }
-        *reinterpret_cast<float4 *>(grad + sg.dst + 4 * t) = acc;
+        for (; s < s1; ++s) { const float4 v = p[(long long)s * st4]; acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+        float4 tot = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int base = (threadIdx.x & 63) & ~7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            tot.x = tot.x + __shfl(acc.x, base + j, 64); tot.y = tot.y + __shfl(acc.y, base + j, 64);
+            tot.z = tot.z + __shfl(acc.z, base + j, 64); tot.w = tot.w + __shfl(acc.w, base + j, 64);
+        }
+        if (g == 0) {
+            if (sg.div != 1.0f) { tot.x = __fdiv_rn(tot.x, sg.div); tot.y = __fdiv_rn(tot.y, sg.div); tot.z = __fdiv_rn(tot.z, sg.div); tot.w = __fdiv_rn(tot.w, sg.div); }
+            *reinterpret_cast<float4 *>(grad + sg.dst + 4 * unit) = tot;
+        }
         return;
     }
+    if (t >= sg.n) return;       // padding of a scalar segment
     const long long src = sg.adv ? (long long)(1 + t % sg.adv) * CNN_F + t / sg.adv : t;
     const float *p = sg.slab + src;
     float acc = 0.0f;
@@ -767,7 +781,7 @@ template <typename TC>
 __global__ void __launch_bounds__(256)
 k_cnn_scatter(CnnOffs o, CnnShadows<TC> sh, const float *__restrict__ P) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < o.P) scatter_shadows<TC>(o, sh, i, P[i]);
+    if (i < o.P && !(i >= o.o_w[3] && i < o.o_b[3])) scatter_shadows<TC>(o, sh, i, P[i]);      // fc weights: k_cnn_fc_leaf
 }
 
 // optax adam / adamw element (adam_elem, dqn_net_common.h) + shadow refresh; the step counters live in CnnOptState and are
@@ -781,7 +795,7 @@ __global__ void __launch_bounds__(256)
 k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, float *P, const float *__restrict__ grad, float *mu, float *nu,
            int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= o.P) return;
+    if (i >= o.P || (i >= o.o_w[3] && i < o.o_b[3])) return;          // fc weights: k_cnn_fc_leaf
     const AdamCoef c{(float)(1.0 - st->b1pow), (float)(1.0 - st->b2pow), 1.0f - b1, 1.0f - b2, -st->lr};
     const float gi = grad[i] * grad_scale;
     const float mm = (b1 * mu[i]) + (c.omb1 * gi);
@@ -794,6 +808,45 @@ k_cnn_adam(CnnOffs o, CnnShadows<TC> sh, const CnnOptState *__restrict__ st, flo
     p = p + (c.neglr * u);
     P[i] = p;
     scatter_shadows<TC>(o, sh, i, p);
+}
+
+// The fc weight leaf [3136][512] (95 % of the parameters): its forward shadow is the transpose, and written element by element
+// (k_cnn_scatter / k_cnn_adam's first form) that is 1.6 M scattered 2-byte stores. Here a workgroup takes a 64 x 64 tile: Adam
+// (ADAM) or a plain copy on coalesced rows, the new values through an LDS tile, the transposed shadow as 64-element runs.
+template <typename TC, bool ADAM>
+__global__ void __launch_bounds__(256)
+k_cnn_fc_leaf(CnnOffs o, TC *__restrict__ wt, TC *__restrict__ wb, const CnnOptState *__restrict__ st, float *P, const float *__restrict__ grad, float *mu, float *nu,
+              int adamw, float b1, float b2, float eps, float wd, float grad_scale) {
+    constexpr int K = 3136, N = 512;
+    __shared__ float tile[64][65];
+    const int k0 = (blockIdx.x / (N / 64)) * 64, n0 = (blockIdx.x % (N / 64)) * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    AdamCoef c{};
+    if constexpr (ADAM) c = AdamCoef{(float)(1.0 - st->b1pow), (float)(1.0 - st->b2pow), 1.0f - b1, 1.0f - b2, -st->lr};
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int kk = ty + 4 * u;
+        const long long e = (long long)(k0 + kk) * N + n0 + tx, i = o.o_w[3] + e;
+        float p = P[i];
+        if constexpr (ADAM) {
+            const float gi = grad[i] * grad_scale;
+            const float mm = (b1 * mu[i]) + (c.omb1 * gi);
+            const float vv = (b2 * nu[i]) + (c.omb2 * (gi * gi));
+            mu[i] = mm; nu[i] = vv;
+            const float mhat = __fdiv_rn(mm, c.c1), vhat = __fdiv_rn(vv, c.c2);
+            float upd = __fdiv_rn(mhat, sqrtf(vhat) + eps);
+            if (adamw) upd = upd + (wd * p);
+            p = p + (c.neglr * upd);
+            P[i] = p;
+        }
+        wb[e] = (TC)p;
+        tile[kk][tx] = p;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int nn = ty + 4 * u;
+        wt[(long long)(n0 + nn) * K + k0 + tx] = (TC)tile[tx][nn];
+    }
 }
 
 // ------------------------------------------------------------------------------------ frame replay ring (configs[4] loop)
@@ -959,8 +1012,16 @@ extern "C" int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n) {
 
 static void cnn_refresh_shadows(dqn_cnn_handle *h, int which, hipStream_t s) {
     const unsigned blocks = (unsigned)((h->P + 255) / 256);
-    if (h->bf16) hipLaunchKernelGGL((k_cnn_scatter<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, which), h->params[which]);
-    else hipLaunchKernelGGL((k_cnn_scatter<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, which), h->params[which]);
+    const unsigned fcb = (3136 / 64) * (512 / 64);
+    if (h->bf16) {
+        hipLaunchKernelGGL((k_cnn_scatter<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, which), h->params[which]);
+        hipLaunchKernelGGL((k_cnn_fc_leaf<__bf16, false>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (__bf16 *)h->wt[which][3], (__bf16 *)h->wb[which][3], nullptr, h->params[which],
+                           nullptr, nullptr, nullptr, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        hipLaunchKernelGGL((k_cnn_scatter<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, which), h->params[which]);
+        hipLaunchKernelGGL((k_cnn_fc_leaf<float, false>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (float *)h->wt[which][3], (float *)h->wb[which][3], nullptr, h->params[which],
+                           nullptr, nullptr, nullptr, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f);
+    }
 }
 
 // which: DQN_NET_ONLINE / DQN_NET_TARGET. Flat f32: conv1 w[8,8,4,32] b[32] conv2 w[4,4,32,64] b[64] conv3 w[3,3,64,64] b[64]
@@ -1068,10 +1129,14 @@ template <typename TI, typename TC, int L>
 static void launch_dw(dqn_cnn_handle *h, hipStream_t s, int B, const TI *in, const TC *dz, CnnSegs &segs, int &nseg, float div) {
     typedef CnnGeo<L> G;
     const int M = B * G::OH * G::OW, rows = dw_rows_per_slice(h, L, M), S = (M + rows - 1) / rows, tiles = dw_shape(L, h->bf16).tiles;
+    if (S == 1 && div == 1.0f) {          // one slice: the kernel writes the leaf itself (the fc layer at B = 512: 6.4 MB less to write and re-read)
+        DQN_LAUNCH((k_cnn_dw<TI, TC, L>), dim3((unsigned)tiles), dim3(256), 0, s, M, rows, in, dz, h->grad + h->L[L].o_w, h->grad + h->L[L].o_b);
+        return;
+    }
     DQN_LAUNCH((k_cnn_dw<TI, TC, L>), dim3((unsigned)(tiles * S)), dim3(256), 0, s, M, rows, in, dz, h->slab[L], h->bslab[L]);
     const long long nw = (long long)h->L[L].K * h->L[L].N, nb = h->L[L].N;
-    segs.s[nseg++] = CnnSeg{h->slab[L], nw, h->L[L].o_w, nw, nw / 4, S, 0, div};
-    segs.s[nseg++] = CnnSeg{h->bslab[L], nb, h->L[L].o_b, nb, nb / 4, S, 0, 1.0f};
+    segs.s[nseg++] = CnnSeg{h->slab[L], nw, h->L[L].o_w, nw, nw / 4 * 8, S, 0, div, 1};              // vector segments: 8 lanes per float4
+    segs.s[nseg++] = CnnSeg{h->bslab[L], nb, h->L[L].o_b, nb, nb / 4 * 8, S, 0, 1.0f, 1};
 }
 template <typename TC, int L>
 static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
@@ -1088,10 +1153,10 @@ static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, (TC *)h->dz[3], h->hslab, h->hbslab,
                        h->loss_part);
     CnnSegs segs{}; int nseg = 0;
-    segs.s[nseg++] = CnnSeg{h->hslab, CNN_F, h->o_wv, 16 * CNN_F, CNN_F / 4, blocks, 0, 1.0f};
-    segs.s[nseg++] = CnnSeg{h->hbslab, 1, h->o_bv, 16, 1, blocks, 0, 1.0f};
-    segs.s[nseg++] = CnnSeg{h->hslab, (long long)CNN_F * h->A, h->o_wa, 16 * CNN_F, (long long)CNN_F * h->A, blocks, h->A, 1.0f};
-    segs.s[nseg++] = CnnSeg{h->hbslab + 1, h->A, h->o_ba, 16, h->A, blocks, 0, 1.0f};
+    segs.s[nseg++] = CnnSeg{h->hslab, CNN_F, h->o_wv, 16 * CNN_F, CNN_F / 4 * 8, blocks, 0, 1.0f, 1};
+    segs.s[nseg++] = CnnSeg{h->hbslab, 1, h->o_bv, 16, 8, blocks, 0, 1.0f, 0};
+    segs.s[nseg++] = CnnSeg{h->hslab, (long long)CNN_F * h->A, h->o_wa, 16 * CNN_F, ((long long)CNN_F * h->A + 7) / 8 * 8, blocks, h->A, 1.0f, 0};
+    segs.s[nseg++] = CnnSeg{h->hbslab + 1, h->A, h->o_ba, 16, (h->A + 7) / 8 * 8, blocks, 0, 1.0f, 0};
     // dW_l needs dZ_l only: layers 3..1 go to the side stream as soon as their dZ exists, the chain dZ4 -> dZ3 -> dZ2 -> dZ1 -> dW_conv1
     // stays on the caller's stream (fork / join by events: also valid inside a stream capture)
     hipStream_t sd = h->side ? h->side : s;
@@ -1140,10 +1205,18 @@ extern "C" int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr,
 
 static int cnn_adam(dqn_cnn_handle *h, float grad_scale, hipStream_t s) {
     const unsigned blocks = (unsigned)((h->P + 255) / 256);
-    if (h->bf16) hipLaunchKernelGGL((k_cnn_adam<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
-                                    h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
-    else hipLaunchKernelGGL((k_cnn_adam<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
-                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+    const unsigned fcb = (3136 / 64) * (512 / 64);
+    if (h->bf16) {
+        hipLaunchKernelGGL((k_cnn_fc_leaf<__bf16, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (__bf16 *)h->wt[0][3], (__bf16 *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
+                           h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+        hipLaunchKernelGGL((k_cnn_adam<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
+                           h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+    } else {
+        hipLaunchKernelGGL((k_cnn_fc_leaf<float, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (float *)h->wt[0][3], (float *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
+                           h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+        hipLaunchKernelGGL((k_cnn_adam<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
+                           h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
+    }
     CNN_TRY(hipGetLastError());
     return DQN_OK;
 }
