@@ -890,6 +890,7 @@ struct dqn_cnn_handle {
     void *wb[2][4] = {{nullptr}};                      // backward-data shadows (BwdGeo; [1..3])
     float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads, output-major [16][512] (0 = val, 1.. = adv), biases [1 + A]
     void *act[4] = {nullptr};                          // layer outputs (kept for the backward)
+    void *act_t[4] = {nullptr};                        // the target pass of dqn_cnn_update (runs beside the online pass)
     void *dz[4] = {nullptr};                           // gradients at the layers' pre-activations (same shapes)
     float *q[3] = {nullptr, nullptr, nullptr};         // Q of the three passes of compute_q_targets
     float *scratch = nullptr;
@@ -900,7 +901,7 @@ struct dqn_cnn_handle {
     void *ring_arena = nullptr; long long ring_cap = 0, ring_counter = 0;
     uint8_t *ring_s = nullptr, *ring_s2 = nullptr, *stage_s = nullptr, *stage_s2 = nullptr; int32_t *ring_a = nullptr, *stage_a = nullptr;
     float *ring_r = nullptr, *ring_d = nullptr, *stage_r = nullptr, *stage_d = nullptr, *td = nullptr;
-    hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
+    hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
 };
 
@@ -919,6 +920,12 @@ static int dw_rows_per_slice(const dqn_cnn_handle *h, int l, long long M) {
     const DwShape d = dw_shape(l, h->bf16);
     const long long per = (M + (long long)h->smax[l] * d.unit - 1) / ((long long)h->smax[l] * d.unit);
     return (int)(per < 1 ? 1 : per) * d.unit;
+}
+
+static int dw_slices(const dqn_cnn_handle *h, int l, int B) {
+    const long long M = (long long)B * cnn_shape(l).positions;
+    const int rows = dw_rows_per_slice(h, l, M);
+    return (int)((M + rows - 1) / rows);
 }
 
 static CnnOffs cnn_offs(const dqn_cnn_handle *h) {
@@ -962,7 +969,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     }
     const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
     size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 6 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
-    for (int l = 0; l < 4; ++l) total += 3 * sz_act[l] + sz_slab[l] + sz_bslab[l];
+    for (int l = 0; l < 4; ++l) total += 4 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
     char *c = (char *)h->arena;
@@ -973,7 +980,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh);
     }
     h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
-    for (int l = 0; l < 4; ++l) { h->act[l] = take(2 * sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
+    for (int l = 0; l < 4; ++l) { h->act[l] = take(2 * sz_act[l]); h->act_t[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
     h->q[0] = (float *)take(2 * sz_q); h->q[1] = nullptr; h->q[2] = (float *)take(sz_q);      // q[0]: [2 B][A] of the paired online pass
     h->targets = (float *)take(sz_q);
     h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
@@ -982,7 +989,8 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     h->hslab = (float *)take(sz_hslab); h->hbslab = (float *)take(sz_hbslab);
     (void)hipMemset(h->arena, 0, total);
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess) {
-        bool ok = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess
+                  && hipEventCreateWithFlags(&h->ev_tgt, hipEventDisableTiming) == hipSuccess;
         for (int l = 1; l < 4; ++l) ok = ok && hipEventCreateWithFlags(&h->ev_dz[l], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
     } else h->side = nullptr;
@@ -998,6 +1006,8 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (h->side) (void)hipStreamDestroy(h->side);
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_tgt) (void)hipEventDestroy(h->ev_tgt);
     if (h->arena) (void)hipFree(h->arena);
     if (h->ring_arena) (void)hipFree(h->ring_arena);
     delete h;
@@ -1087,18 +1097,19 @@ static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int 
 
 // one pass over B1 frame stacks from `frames` followed by B2 from `frames2` (B2 = 0: a plain forward); q: [B1 + B2][A]
 template <typename TC>
-static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s) {
+static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act) {
     const float *P = h->params[which];
     const int B = B1 + B2;
-    TC *a0 = (TC *)h->act[0], *a1 = (TC *)h->act[1], *a2 = (TC *)h->act[2], *a3 = (TC *)h->act[3];
+    TC *a0 = (TC *)act[0], *a1 = (TC *)act[1], *a2 = (TC *)act[2], *a3 = (TC *)act[3];
     launch_layer<uint8_t, TC, 0>(s, B, frames, frames2 ? frames2 : frames, B1, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
     launch_layer<TC, TC, 1>(s, B, a0, a0, B, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
     launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
     launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3);
     hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
-static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s) {
-    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s);
+static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr) {
+    if (!act) act = h->act;
+    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
@@ -1147,8 +1158,9 @@ static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
 }
 
 // backward from the activations the last online forward left in the handle and its predictions q
+// returns true when the fc weight leaf has been stepped already (prep_opt: dqn_cnn_update; only then)
 template <typename TC>
-static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt) {
+static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt) {
     const int blocks = (B + 15) / 16;
     hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, (TC *)h->dz[3], h->hslab, h->hbslab,
                        h->loss_part);
@@ -1165,6 +1177,14 @@ static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     launch_dw<TC, TC, 3>(h, sd, B, (const TC *)h->act[2], (const TC *)h->dz[3], segs, nseg, 1.0f);
     launch_bwd_data<TC, 3>(h, s, B);
     if (h->side) { (void)hipEventRecord(h->ev_dz[2], s); (void)hipStreamWaitEvent(sd, h->ev_dz[2], 0); }
+    // the fc leaf (95 % of the parameters) is complete when its single-slice dW is (written straight into the gradient) and
+    // backward-data has read the fc weights for the last time: its Adam step goes here, beside the rest of the backward
+    bool fc_done = false;
+    if (prep_opt && h->side && dw_slices(h, 3, B) == 1) {
+        hipLaunchKernelGGL((k_cnn_fc_leaf<TC, true>), dim3((3136 / 64) * (512 / 64)), dim3(256), 0, sd, cnn_offs(h), (TC *)h->wt[0][3], (TC *)h->wb[0][3], h->opt, h->params[0], h->grad,
+                           h->mu, h->nu, h->adamw, h->b1, h->b2, h->eps, h->wd, 1.0f);
+        fc_done = true;
+    }
     launch_dw<TC, TC, 2>(h, sd, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
     launch_bwd_data<TC, 2>(h, s, B);
     if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd, h->ev_dz[1], 0); }
@@ -1176,6 +1196,7 @@ static void cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     for (int i = 0; i < nseg; ++i) total += segs.s[i].units;
     segs.count = nseg;
     hipLaunchKernelGGL(k_cnn_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs, total, h->grad, h->loss_part, blocks, B, h->loss);
+    return fc_done;
 }
 
 /* gradient of compute_loss (q_learning_functions.py:31-39: mean_i w_i sum_a huber(model(s_i)[a] - targets[i][a])) w.r.t. every
@@ -1203,16 +1224,16 @@ extern "C" int dqn_cnn_set_optimizer(dqn_cnn_handle *h, int32_t adamw, float lr,
     return DQN_OK;
 }
 
-static int cnn_adam(dqn_cnn_handle *h, float grad_scale, hipStream_t s) {
+static int cnn_adam(dqn_cnn_handle *h, float grad_scale, hipStream_t s, bool fc_done = false) {
     const unsigned blocks = (unsigned)((h->P + 255) / 256);
     const unsigned fcb = (3136 / 64) * (512 / 64);
     if (h->bf16) {
-        hipLaunchKernelGGL((k_cnn_fc_leaf<__bf16, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (__bf16 *)h->wt[0][3], (__bf16 *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
+        if (!fc_done) hipLaunchKernelGGL((k_cnn_fc_leaf<__bf16, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (__bf16 *)h->wt[0][3], (__bf16 *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
         hipLaunchKernelGGL((k_cnn_adam<__bf16>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<__bf16>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
     } else {
-        hipLaunchKernelGGL((k_cnn_fc_leaf<float, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (float *)h->wt[0][3], (float *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
+        if (!fc_done) hipLaunchKernelGGL((k_cnn_fc_leaf<float, true>), dim3(fcb), dim3(256), 0, s, cnn_offs(h), (float *)h->wt[0][3], (float *)h->wb[0][3], h->opt, h->params[0], h->grad, h->mu, h->nu,
                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
         hipLaunchKernelGGL((k_cnn_adam<float>), dim3(blocks), dim3(256), 0, s, cnn_offs(h), cnn_shadows<float>(h, 0), h->opt, h->params[0], h->grad, h->mu, h->nu,
                            h->adamw, h->b1, h->b2, h->eps, h->wd, grad_scale);
@@ -1244,13 +1265,17 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
     int rc = DQN_OK;
-    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], st);                             // :54
-    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // :52, :53 in one pass; s's activations are rows [0, B)
+    // the target pass (:54) runs on the side stream in its own activation buffers, beside the online pass over s and s' (:52, :53)
+    if (h->side) { (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(h->side, h->ev_fork, 0); }
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t);
+    if (h->side) (void)hipEventRecord(h->ev_tgt, h->side);
+    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // one pass; s's activations are rows [0, B)
+    if (h->side) (void)hipStreamWaitEvent(st, h->ev_tgt, 0);
     launch_td(st, h->q[0], h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, nullptr, gamma, B, h->A, h->targets, td_abs_out ? h->td : nullptr, nullptr, nullptr, h->scratch);
     if (td_abs_out) hipLaunchKernelGGL(k_cnn_abs, dim3((B + 255) / 256), dim3(256), 0, st, h->td, B, td_abs_out);
-    if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true); else cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
+    const bool fc_done = h->bf16 ? cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true) : cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
     CNN_TRY(hipGetLastError());
-    rc = cnn_adam(h, 1.0f, st); if (rc) return rc;
+    rc = cnn_adam(h, 1.0f, st, fc_done); if (rc) return rc;
     if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
     return DQN_OK;
 }
