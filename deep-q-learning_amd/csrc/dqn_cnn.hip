@@ -621,18 +621,30 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
 // workgroup's share of the head leaves: 16 rows per workgroup = one slice of the head slabs
 //   hslab[blk][j][k] = sum_{its rows} a3[i][k] gd[i][j]   (j = 0: val, 1..A: adv),   hbslab[blk][j] = sum gd[i][j]
 // (k_cnn_reduce adds the slices in order); one loss partial per workgroup.
+struct CnnTdArgs { const float *nq, *nt; const int32_t *a; const float *r, *d; float gamma; float *td_abs; };     // nq == nullptr: targets are given
 template <typename TC>
 __global__ void __launch_bounds__(256)
 k_cnn_head_bwd(const float *__restrict__ q, const float *__restrict__ targets, const float *__restrict__ isw, const TC *__restrict__ feat,
                const float *__restrict__ wht, int A, int B, TC *__restrict__ dz4, float *__restrict__ hslab, float *__restrict__ hbslab,
-               float *__restrict__ loss_part) {
-    __shared__ float lg[16 * 16], lrow[16];
+               float *__restrict__ loss_part, CnnTdArgs td) {
+    __shared__ float lg[16 * 16], lrow[16], ltg[16 * 16];
     const int tid = threadIdx.x, r0 = blockIdx.x * 16;
+    if (td.nq) {                                                   // the TD rule (q_learning_functions.py:55-60, td_row) instead of given targets
+        if (tid < 16 && r0 + tid < B) {
+            const int i = r0 + tid;
+            float qr[16], nqr[16], ntr[16], tr[16];
+            for (int k = 0; k < A; ++k) { qr[k] = q[(long long)i * A + k]; nqr[k] = td.nq[(long long)i * A + k]; ntr[k] = td.nt[(long long)i * A + k]; }
+            const float delta = td_row(qr, nqr, ntr, td.a[i], td.r[i], td.d[i], td.gamma, A, tr);
+            for (int k = 0; k < A; ++k) ltg[16 * tid + k] = tr[k];
+            if (td.td_abs) td.td_abs[i] = fabsf(delta);
+        }
+        __syncthreads();
+    }
     {                                                              // thread (row, j): one Q entry
         const int row = tid >> 4, j = tid & 15, i = r0 + row;
         const bool on = i < B && j < A;
         float e = 0.0f, w = 1.0f;
-        if (on) { e = q[(long long)i * A + j] - targets[(long long)i * A + j]; if (isw) w = isw[i]; }
+        if (on) { e = q[(long long)i * A + j] - (td.nq ? ltg[16 * row + j] : targets[(long long)i * A + j]); if (isw) w = isw[i]; }
         const float cpd = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
         const float g = on ? (w * cpd) * __fdiv_rn(1.0f, (float)B) : 0.0f;
         float hub = on ? huber(e) : 0.0f, gsum = g;
@@ -871,10 +883,6 @@ k_cnn_gather(const uint8_t *__restrict__ ring_s, const uint8_t *__restrict__ rin
     for (int u = 0; u < 7; ++u) { const int p = threadIdx.x + 256 * u; if (p < CNN_FRAME_BYTES / 16) dst[p] = v[u]; }
     if (part == 0 && threadIdx.x == 0) { a[i] = ring_a[row]; r[i] = ring_r[row]; d[i] = ring_d[row]; }
 }
-__global__ void __launch_bounds__(256) k_cnn_abs(const float *__restrict__ x, int n, float *__restrict__ y) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = fabsf(x[i]);
-}
 
 // ------------------------------------------------------------------------------------ C ABI
 #define CNN_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return dqn_set_error(DQN_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); } while (0)
@@ -900,7 +908,7 @@ struct dqn_cnn_handle {
     // frame replay ring (dqn_cnn_replay_init)
     void *ring_arena = nullptr; long long ring_cap = 0, ring_counter = 0;
     uint8_t *ring_s = nullptr, *ring_s2 = nullptr, *stage_s = nullptr, *stage_s2 = nullptr; int32_t *ring_a = nullptr, *stage_a = nullptr;
-    float *ring_r = nullptr, *ring_d = nullptr, *stage_r = nullptr, *stage_d = nullptr, *td = nullptr;
+    float *ring_r = nullptr, *ring_d = nullptr, *stage_r = nullptr, *stage_d = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
 };
@@ -984,7 +992,6 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     h->q[0] = (float *)take(2 * sz_q); h->q[1] = nullptr; h->q[2] = (float *)take(sz_q);      // q[0]: [2 B][A] of the paired online pass
     h->targets = (float *)take(sz_q);
     h->scratch = (float *)take(al((size_t)max_batch * 4)); h->loss_part = (float *)take(al((size_t)max_batch * 4));
-    h->td = (float *)take(al((size_t)max_batch * 4));
     h->loss = (float *)take(256); h->opt = (CnnOptState *)take(256);
     h->hslab = (float *)take(sz_hslab); h->hbslab = (float *)take(sz_hbslab);
     (void)hipMemset(h->arena, 0, total);
@@ -1160,10 +1167,11 @@ static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
 // backward from the activations the last online forward left in the handle and its predictions q
 // returns true when the fc weight leaf has been stepped already (prep_opt: dqn_cnn_update; only then)
 template <typename TC>
-static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt) {
+static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt,
+                           const CnnTdArgs &td = CnnTdArgs{}) {
     const int blocks = (B + 15) / 16;
     hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, (TC *)h->dz[3], h->hslab, h->hbslab,
-                       h->loss_part);
+                       h->loss_part, td);
     CnnSegs segs{}; int nseg = 0;
     segs.s[nseg++] = CnnSeg{h->hslab, CNN_F, h->o_wv, 16 * CNN_F, CNN_F / 4 * 8, blocks, 0, 1.0f, 1};
     segs.s[nseg++] = CnnSeg{h->hbslab, 1, h->o_bv, 16, 8, blocks, 0, 1.0f, 0};
@@ -1271,9 +1279,9 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     if (h->side) (void)hipEventRecord(h->ev_tgt, h->side);
     cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // one pass; s's activations are rows [0, B)
     if (h->side) (void)hipStreamWaitEvent(st, h->ev_tgt, 0);
-    launch_td(st, h->q[0], h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, nullptr, gamma, B, h->A, h->targets, td_abs_out ? h->td : nullptr, nullptr, nullptr, h->scratch);
-    if (td_abs_out) hipLaunchKernelGGL(k_cnn_abs, dim3((B + 255) / 256), dim3(256), 0, st, h->td, B, td_abs_out);
-    const bool fc_done = h->bf16 ? cnn_backward_t<__bf16>(h, s, h->q[0], h->targets, isw, B, st, true) : cnn_backward_t<float>(h, s, h->q[0], h->targets, isw, B, st, true);
+    // the TD rule (:55-60) is the first thing the head-backward kernel does with the three Q tensors
+    const CnnTdArgs td{h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, gamma, td_abs_out};
+    const bool fc_done = h->bf16 ? cnn_backward_t<__bf16>(h, s, h->q[0], nullptr, isw, B, st, true, td) : cnn_backward_t<float>(h, s, h->q[0], nullptr, isw, B, st, true, td);
     CNN_TRY(hipGetLastError());
     rc = cnn_adam(h, 1.0f, st, fc_done); if (rc) return rc;
     if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
