@@ -482,7 +482,7 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
     constexpr int LSA = TR ? MR + 8 : KT + 4, LSB = TR ? MR + 8 : NT + 4;      // row length of the images
     constexpr int APR = KT / 8, BPR = NT / 8;                         // pieces per row m
     constexpr int APT = MR * APR / 256, BPT = MR * BPR / 256;
-    constexpr int LBUF = TR ? 2 : 1;
+    constexpr int LBUF = (TR && L != 0) ? 2 : 1;       // conv1: one 42 KB image set, three workgroups per CU
     static_assert(WK * WN == 4 && K % KT == 0 && N % NT == 0 && (KT % ROWLEN == 0 || ROWLEN % KT == 0), "tile shape");
     static_assert(MR * APR % 256 == 0 && MR * BPR % 256 == 0 && NSC % R == 0 && TK >= 1 && TN >= 1 && 256 % MR == 0, "piece split");
     typedef typename RawPiece<TI>::t RA;
@@ -963,7 +963,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         h->L[l] = CnnLayer{g.K, g.OC, p, p + (long long)g.K * g.OC};
         p += (long long)g.K * g.OC + g.OC;
         const int t = dw_shape(l, h->bf16).tiles;
-        h->smax[l] = t >= h->num_cus ? 1 : (t > h->num_cus / 2 ? 2 : h->num_cus / t);
+        h->smax[l] = t >= h->num_cus ? 1 : (t > h->num_cus / 2 ? 2 : (l == 0 ? 2 : 1) * h->num_cus / t);
     }
     h->o_wv = p; p += 512; h->o_bv = p; p += 1; h->o_wa = p; p += 512ll * h->A; h->o_ba = p; p += h->A; h->P = p;
     const size_t esz = h->bf16 ? 2 : 4;
