@@ -400,7 +400,7 @@ def per_sample_lines(dq, rank):
 def cnn_lines(dq):
     """BASELINE.json configs[4] (PongNoFrameskip-v4 shape, 512 envs): the Nature-CNN dueling Q-net (dqn_cnn.hip) on 512 frame
     stacks -- the forward (five launches) and one whole Agent._step on a given minibatch (dqn_cnn_update: three forwards, TD
-    rule, loss gradient through the CNN, AdamW, shadow refresh), HIP events around 20 back-to-back calls"""
+    rule, loss gradient through the CNN, AdamW, shadow refresh), HIP events around back-to-back calls (median of 5 regions of 10)"""
     out = {}
     Bc, A_, flop = 512, 6, 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7)
     bwd = 2 * (2 * (81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7) + 400 * 32 * 256)      # dX and dW per layer; conv1 has no dX
@@ -419,14 +419,17 @@ def cnn_lines(dq):
                  "BASELINE configs[4] forward: 5 launches, launch gaps included"),
                 (f"cnn_update_B{Bc}_{prec}", lambda: e.update(frames, act, r, frames2, d), 3 * flop + bwd,
                  "BASELINE configs[4] Agent._step on a given minibatch: 3 forwards + TD + backward (3 dX, 4 dW) + reduce + AdamW, ~27 launches on two streams")):
-            for _ in range(3):
+            for _ in range(5):
                 fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(); e0.record()
-            for _ in range(20):
-                fn()
-            e1.record(); e1.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / 20
+            reps = []
+            for _ in range(5):                      # median of 5 regions of 10 calls (a first region was seen 3x slow once: allocation transients)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record(); e1.synchronize()
+                reps.append(e0.elapsed_time(e1) * 1e3 / 10)
+            us = float(np.median(reps))
             out[name] = {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": fl * Bc / us / 1e6, "peak": peak,
                          "unit": "TFLOP/s", "frac": fl * Bc / us / 1e6 / peak, "traffic": None, "note": note}
         e.close()
