@@ -38,6 +38,8 @@ for _ in range(a.reps):
     step()
 e1.record(); e1.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.reps
-gf = 9.57e9 * B / 512 * (1 if a.mode == "forward" else 5)       # update: three forwards + backward-data + dW = 5 forward-equivalents (conv1 has no dX)
+fwd = 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7)
+bwd = 2 * (2 * (81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7) + 400 * 32 * 256)      # dX and dW per layer; conv1 has no dX
+gf = B * (fwd if a.mode == "forward" else 3 * fwd + bwd)
 print(a.precision, a.mode, "B", B, "us", round(us, 1), "TF", round(gf / us * 1e-6, 1))
 e.close()
