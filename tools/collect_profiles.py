@@ -45,7 +45,7 @@ for part in ("bench", "big", "cnn", "cnnf32"):                               # M
         mf.update({k: v for k, v in json.load(open(f2)).items() if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0})
 if mf:
     json.dump(mf, open(f"profiles/{rnd}_pmc_mfma.json", "w"), indent=1)
-for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"), (f"gpurun_out/cnn_{tag}.txt", f"profiles/{rnd}_cnn_kernels.txt"),
+for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"), (f"gpurun_out/cnn_{tag}.txt", f"profiles/{rnd}_cnn_kernels.txt"), (f"gpurun_out/cnn_sweep_{tag}.json", f"profiles/{rnd}_cnn_sweep.json"),
                  (f"gpurun_out/probe_{tag}.json", f"profiles/{rnd}_per_sample_probe.json")):
     if os.path.exists(src):
         shutil.copy(src, dst)

@@ -19,3 +19,4 @@ cd $R
 python tools/per_sample_probe.py --json $out/probe_$tag.json 2>&1 | tail -8
 python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
 python tools/sweep.py --max-log2 17 --no-actor --precision bf16 --json $out/sweep_${tag}_bf16.json 2>&1 | tail -2 | cut -c1-300
+python tools/cnn_sweep.py --json $out/cnn_sweep_$tag.json 2>&1 | tail -8 | cut -c1-260
