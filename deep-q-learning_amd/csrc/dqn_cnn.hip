@@ -1,19 +1,20 @@
-// csrc/dqn_cnn.hip -- Nature-CNN dueling Q-network, forward (BASELINE configs[4]: PongNoFrameskip-v4 shape, SURVEY.md 8(f)
-// rank 4). Not in the reference, which has only the MLP of LunarLander/dddqn.py:19-22; the trunk ends in the reference's
-// dueling head (dddqn.py:29-31: Q = val + adv - mean(adv)) and its Q values feed the reference's TD rule unchanged
-// (General/QLearning/q_learning_functions.py:55-60, k_td).
+// csrc/dqn_cnn.hip -- Nature-CNN dueling Q-network for BASELINE configs[4] (PongNoFrameskip-v4 shape):
+// forward, loss gradient, AdamW step, Agent._step on a given minibatch or from a ring of u8 frame stacks, epsilon-greedy acting.
+// Not in the reference, which has only the MLP of LunarLander/dddqn.py:19-22; the trunk ends in the reference's dueling head
+// (dddqn.py:29-31: Q = val + adv - mean(adv)), its Q values feed the reference's TD rule unchanged
+// (General/QLearning/q_learning_functions.py:55-60, td_row), its loss is the reference's (:31-39).
 //
 //   frames u8 [B][84][84][4] (NHWC, 4 stacked frames) / 255
 //   conv1 32 x 8x8 / 4 -> [B][20][20][32]   conv2 64 x 4x4 / 2 -> [B][9][9][64]   conv3 64 x 3x3 / 1 -> [B][7][7][64]
 //   fc 3136 -> 512, ReLU after each; val 512 -> 1, adv 512 -> A
 //
-// Every layer is ONE implicit GEMM kernel, Out[M][N] = relu(Patch[M][K] . W[K][N] + b): row m = output position
-// (b, oh, ow), k = (kh, kw, c) -- in NHWC a patch row (kh fixed) is KW*IC contiguous elements, a multiple of the 32-deep
-// k-chunk for every layer, so a chunk of a row is one contiguous run: gathered straight from the activation tensor into
-// an LDS image, no im2col buffer. Weights are kept transposed ([N][K], k contiguous) so that both MFMA operands are
-// 16-byte LDS reads of consecutive k.
-//   precision bf16: v_mfma_f32_32x32x16_bf16, activations / weights bf16, f32 accumulate (tolerance 2e-2 of scale)
-//   precision f32 : v_mfma_f32_32x32x2_f32, exact: every output is the k-ascending fmaf chain of the CPU restatement
+// Forward: every layer is ONE implicit GEMM kernel, Out[M][N] = relu(Patch[M][K] . W[K][N] + b): row m = output position
+// (b, oh, ow), k = (kh, kw, c) -- in NHWC a patch row (kh fixed) is KW*IC contiguous elements, a multiple of 8 for every layer,
+// so 8-element pieces are gathered straight from the activation tensor into an LDS image, no im2col buffer. Weights are kept
+// transposed ([N][K], k contiguous) so that both MFMA operands are 16-byte LDS reads of consecutive k.
+//   precision bf16: v_mfma_f32_32x32x16_bf16 / 16x16x32, activations / weights bf16, f32 accumulate (tolerance 2e-2 of scale)
+//   precision f32 : v_mfma_f32_32x32x2_f32 / 16x16x4, exact: every output is the k-ascending fmaf chain of the CPU restatement
+// Backward: see the section "backward (loss gradient)" below; host side and C ABI at the end of the file.
 #include "../../include/dqn_hip.h"
 #include "dqn_device.h"
 #include "dqn_launch.h"
@@ -26,8 +27,7 @@ typedef float f32x16c __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
 
 // Geometry of the four GEMM layers, compile-time (every index division below folds into shifts / multiplies), with the tile
-// shape chosen per layer: workgroup tile = (MT*WM) rows x (MT*WN) columns, one MT x MT MFMA tile per wave (4 waves), and R =
-// depth of the register prefetch ring (R divides the chunk count K / 64).
+// shape chosen per layer (CnnTile below).
 //   conv1  M = 400 B, K = 256 (4 chunks),  N = 32   128 x 32 tile, everything requested up front
 //   conv2  M =  81 B, K = 512 (8),         N = 64    64 x 64
 //   conv3  M =  49 B, K = 576 (9),         N = 64    64 x 64
