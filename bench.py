@@ -436,7 +436,7 @@ def cnn_lines(dq):
     # the loop around it: 512 synthetic frame-stack envs, 4 vector env steps (act, add to the frame ring and the PER index) per
     # update of 512 PER-sampled transitions (General/QLearning/cnn_agent.py); the synthetic env (torch.randint frames) is inside
     from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
-    ag = CnnVectorAgent(n_envs=Bc, num_actions=A_, capacity=1 << 14, batch_size=Bc, precision="bf16", train_frequency=4, seed=5)
+    ag = CnnVectorAgent(n_envs=Bc, num_actions=A_, capacity=1 << 14, batch_size=Bc, precision="bf16", train_frequency=4, seed=5, n_step=3)
     ag.init_params(torch.randn(ag.cnn.param_count) * 0.02)
     ag.training(3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -449,7 +449,7 @@ def cnn_lines(dq):
     out[f"cnn_loop_{Bc}envs_bf16"] = {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": fl / us / 1e6, "peak": MFMA_BF16_PEAK_TFLOPS,
                                       "unit": "TFLOP/s", "frac": fl / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                                       "updates_per_sec": 1e6 / us, "env_steps_per_sec": 4 * Bc * 1e6 / us, "device_errors": ag.index.device_errors(),
-                                      "note": "BASELINE configs[4] shape on ONE GPU, n_step 1: 4 vector env steps of 512 synthetic frame-stack envs (CNN act + "
+                                      "note": "BASELINE configs[4] shape on ONE GPU, n-step 3 PER: 4 vector env steps of 512 synthetic frame-stack envs (CNN act + "
                                               "frame-ring add + PER index add) + 1 update from the ring (PER sample, gather, 3 forwards, backward, AdamW, priority write-back); "
                                               "host-driven loop (no graph), synthetic env = torch.randint"}
     ag.close()

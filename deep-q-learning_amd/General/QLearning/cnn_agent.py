@@ -6,6 +6,8 @@ numerical step is a C-ABI call:
   add              dqn_cnn_replay_add     (frame ring, replay_buffer.py:58-65)  +  dqn_replay_add on the index engine, whose
                                           sum tree gives the new rows the running maximum priority
   sample           dqn_per_sample         on the index engine (a dqn_handle of the same capacity: positions only)
+  n-step           rows are 1-step; dqn_cnn_update_replay(n_step, n_envs) assembles the n-step transition that starts at a sampled
+                   row from its n - 1 successors; the index is told of a step n - 1 steps late
   update           dqn_cnn_update_replay  (gather, three forwards, TD rule, backward, AdamW; q_agent.py:146-169)
   write-back       dqn_per_update_sorted  with |delta|
 
@@ -23,10 +25,12 @@ from ...engine import Engine, EngineConfig
 class CnnVectorAgent:
     def __init__(self, n_envs=512, num_actions=6, capacity=1 << 14, batch_size=512, precision="bf16", gamma=0.99, epsilon=1.0,
                  epsilon_decay_rate=0.999, min_epsilon=0.1, train_frequency=4, replace_frequency=250, per_beta=0.4, p_done=0.01,
-                 lr=1e-4, seed=0, device=None):
+                 lr=1e-4, seed=0, n_step=1, device=None):
         if capacity % n_envs:
             raise ValueError("capacity must be a multiple of n_envs (whole vector steps per ring lap)")
-        self.n_envs, self.B, self.gamma, self.seed = int(n_envs), int(batch_size), float(gamma), int(seed)
+        if not 1 <= n_step <= 8 or n_step * n_envs > capacity:
+            raise ValueError("n_step must be 1..8 and n_step * n_envs must fit the ring")
+        self.n_envs, self.B, self.gamma, self.seed, self.n_step = int(n_envs), int(batch_size), float(gamma), int(seed), int(n_step)
         self.epsilon, self.decay, self.min_eps = float(epsilon), float(epsilon_decay_rate), float(min_epsilon)
         self.train_frequency, self.replace_frequency, self.per_beta, self.p_done = int(train_frequency), int(replace_frequency), float(per_beta), float(p_done)
         self.cnn = CnnEngine(num_actions=num_actions, max_batch=max(n_envs, batch_size), precision=precision, device=device)
@@ -41,6 +45,7 @@ class CnnVectorAgent:
         self._zeros = (torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.int32, device=dev),
                        torch.zeros((n_envs,), device=dev), torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.uint8, device=dev))
         self.td_abs = torch.empty((self.B,), dtype=torch.float32, device=dev)
+        self._pos = torch.arange(n_envs, dtype=torch.int32, device=dev); self._zero_prio = torch.zeros((n_envs,), dtype=torch.float32, device=dev)
         self.env_steps = self.updates = 0
         self.losses = []
 
@@ -62,14 +67,23 @@ class CnnVectorAgent:
         d = (torch.rand((n,), device=dev, generator=self.gen) < self.p_done).float()
         first = self.cnn.replay_add(self.frames, a, r, nxt, d)
         assert first == (self.env_steps * n) % self.cnn.capacity, (first, self.env_steps)      # the two rings move in lockstep
-        self.index.replay_add(*self._zeros)
+        if self.n_step == 1:
+            self.index.replay_add(*self._zeros)
+        else:
+            # the frame ring holds one row per env step; the n-step transition that starts at a row exists once its n - 1
+            # successors do. So the PER index learns of step t - n + 1 when step t arrives (its own ring counter is n - 1 steps
+            # behind: the same positions), and rows whose frames have just been overwritten are taken out of the draw until then.
+            if self.env_steps * n >= self.cnn.capacity:
+                self.index.per_set(self._pos + first, self._zero_prio)
+            if self.env_steps >= self.n_step - 1:
+                self.index.replay_add(*self._zeros)
         self.frames = nxt
         self.env_steps += 1
         self.epsilon = max(self.epsilon * self.decay, self.min_eps)
 
     def update(self, want_loss=False):
         (_, _, _, _, _), idx, isw = self.index.per_sample(self.B, self.per_beta, self.seed, self.updates)
-        loss = self.cnn.update_from_replay(idx, isw, self.gamma, td_abs_out=self.td_abs, want_loss=want_loss)
+        loss = self.cnn.update_from_replay(idx, isw, self.gamma, td_abs_out=self.td_abs, want_loss=want_loss, n_step=self.n_step, n_envs=self.n_envs)
         self.index.per_update_sorted(idx, self.td_abs)
         self.updates += 1
         if self.updates % self.replace_frequency == 0:
@@ -80,7 +94,7 @@ class CnnVectorAgent:
 
     def training(self, n_updates, warmup_steps=None, want_loss=False):
         """q_agent.py:174-187: act every step, one update per train_frequency steps once the ring holds a batch"""
-        warm = warmup_steps if warmup_steps is not None else (self.B + self.n_envs - 1) // self.n_envs
+        warm = warmup_steps if warmup_steps is not None else (self.B + self.n_envs - 1) // self.n_envs + self.n_step - 1
         while self.env_steps < warm:
             self.env_step()
         for _ in range(n_updates):

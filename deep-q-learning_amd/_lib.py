@@ -97,8 +97,8 @@ SIGNATURES = {
     "dqn_cnn_replay_init": [_P, _I64],
     "dqn_cnn_replay_add": [_P, _P, _P, _P, _P, _P, _I32, C.POINTER(_I64), _P],
     "dqn_cnn_replay_size_host": [_P, C.POINTER(_I64), C.POINTER(_I64)],
-    "dqn_cnn_replay_gather": [_P, _P, _I32, _P, _P, _P, _P, _P, _P],
-    "dqn_cnn_update_replay": [_P, _P, _P, _F, _I32, _P, _P, _P],
+    "dqn_cnn_replay_gather": [_P, _P, _I32, _I32, _I32, _F, _P, _P, _P, _P, _P, _P],
+    "dqn_cnn_update_replay": [_P, _P, _P, _F, _I32, _I32, _I32, _P, _P, _P],
 }
 OTHER = {"dqn_last_error": ([], C.c_char_p), "dqn_abi_version": ([], C.c_int),
          "dqn_default_config": ([C.POINTER(DqnConfig)], None)}

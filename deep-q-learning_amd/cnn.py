@@ -152,20 +152,22 @@ class CnnEngine:
         L.check(self.lib.dqn_cnn_replay_size_host(self.h, C.byref(size), C.byref(ctr)))
         return size.value, ctr.value
 
-    def replay_gather(self, idx):
-        """the rows idx of the ring: (s, a, r, s2, d)"""
+    def replay_gather(self, idx, n_step=1, n_envs=0, gamma=0.99):
+        """the rows idx of the ring: (s, a, r, s2, d); n_step > 1: the n-step transitions that start there (rows stored
+        step-major, n_envs per env step)"""
         idx = self._t(idx, torch.int32); B = idx.numel()
         s = torch.empty((B, 84, 84, 4), dtype=torch.uint8, device=self.device); s2 = torch.empty_like(s)
         a = torch.empty((B,), dtype=torch.int32, device=self.device)
         r = torch.empty((B,), dtype=torch.float32, device=self.device); d = torch.empty_like(r)
-        L.check(self.lib.dqn_cnn_replay_gather(self.h, _ptr(idx), B, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), self._s()))
+        L.check(self.lib.dqn_cnn_replay_gather(self.h, _ptr(idx), B, int(n_step), int(n_envs), float(gamma), _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), self._s()))
         return s, a, r, s2, d
 
-    def update_from_replay(self, idx, isw=None, gamma=0.99, td_abs_out=None, want_loss=False):
-        """Agent._step (q_agent.py:146-169) on the ring rows idx; td_abs_out (float32 [B], optional) receives |delta|"""
+    def update_from_replay(self, idx, isw=None, gamma=0.99, td_abs_out=None, want_loss=False, n_step=1, n_envs=0):
+        """Agent._step (q_agent.py:146-169) on the ring rows idx (n-step transitions when n_step > 1); td_abs_out (float32 [B],
+        optional) receives |delta|"""
         idx = self._t(idx, torch.int32)
         w = None if isw is None else self._t(isw, torch.float32)
         loss = C.c_float(0)
-        L.check(self.lib.dqn_cnn_update_replay(self.h, _ptr(idx), _ptr(w) if w is not None else None, float(gamma), idx.numel(),
+        L.check(self.lib.dqn_cnn_update_replay(self.h, _ptr(idx), _ptr(w) if w is not None else None, float(gamma), int(n_step), int(n_envs), idx.numel(),
                                                _ptr(td_abs_out) if td_abs_out is not None else None, C.byref(loss) if want_loss else None, self._s()))
         return loss.value if want_loss else None

@@ -866,22 +866,36 @@ k_cnn_fc_leaf(CnnOffs o, TC *__restrict__ wt, TC *__restrict__ wb, const CnnOptS
 // (the reference stores both, :28-31), actions i32, rewards f32, dones f32. add = contiguous copies at the ring head (:58-65);
 // the sampled indices come from a PER tree kept by a dqn_handle of the same capacity (host mirror: CnnVectorAgent).
 constexpr int CNN_FRAME_BYTES = 84 * 84 * 4;
-// one workgroup per (sample, s | s'): 1764 16-byte pieces of a row; the scalars ride along in the first workgroups
+// one workgroup per (sample, s | s'): 1764 16-byte pieces of a row; the scalars ride along in the first workgroups.
+// n_step > 1 (SURVEY 8(f) rank 3 for the frame ring): rows are stored one env step each, step-major (row = step * n_envs + env),
+// and the n-step transition that STARTS at the sampled row is put together here from the n rows row + k n_envs: its action, R =
+// r_0 + gamma (r_1 + gamma (...)) cut after the first done (Horner form, the arithmetic of nstep_row in dqn_actor.hip), that done
+// flag, s of the first and s' of the last row. The caller samples only rows whose n - 1 successors are in the ring.
 __global__ void __launch_bounds__(256)
 k_cnn_gather(const uint8_t *__restrict__ ring_s, const uint8_t *__restrict__ ring_s2, const int32_t *__restrict__ ring_a, const float *__restrict__ ring_r,
-             const float *__restrict__ ring_d, const int32_t *__restrict__ idx, int B, long long cap, uint8_t *__restrict__ s, uint8_t *__restrict__ s2,
-             int32_t *__restrict__ a, float *__restrict__ r, float *__restrict__ d) {
+             const float *__restrict__ ring_d, const int32_t *__restrict__ idx, int B, long long cap, int n_step, int n_envs, float gamma,
+             uint8_t *__restrict__ s, uint8_t *__restrict__ s2, int32_t *__restrict__ a, float *__restrict__ r, float *__restrict__ d) {
     const int i = blockIdx.x, part = blockIdx.y;
     long long row = idx[i];
     row = row < 0 ? 0 : (row >= cap ? cap - 1 : row);
-    const uint4 *src = reinterpret_cast<const uint4 *>((part ? ring_s2 : ring_s) + row * CNN_FRAME_BYTES);
+    const long long row_last = (row + (long long)(n_step - 1) * n_envs) % cap;
+    const uint4 *src = reinterpret_cast<const uint4 *>(part ? ring_s2 + row_last * CNN_FRAME_BYTES : ring_s + row * CNN_FRAME_BYTES);
     uint4 *dst = reinterpret_cast<uint4 *>((part ? s2 : s) + (long long)i * CNN_FRAME_BYTES);
     uint4 v[7];
 #pragma unroll
     for (int u = 0; u < 7; ++u) { const int p = threadIdx.x + 256 * u; if (p < CNN_FRAME_BYTES / 16) v[u] = src[p]; }
 #pragma unroll
     for (int u = 0; u < 7; ++u) { const int p = threadIdx.x + 256 * u; if (p < CNN_FRAME_BYTES / 16) dst[p] = v[u]; }
-    if (part == 0 && threadIdx.x == 0) { a[i] = ring_a[row]; r[i] = ring_r[row]; d[i] = ring_d[row]; }
+    if (part == 0 && threadIdx.x == 0) {
+        a[i] = ring_a[row];
+        float rr[8], dd[8];
+        for (int k = 0; k < n_step; ++k) { const long long q = (row + (long long)k * n_envs) % cap; rr[k] = ring_r[q]; dd[k] = ring_d[q]; }
+        int last = n_step - 1;
+        for (int k = n_step - 2; k >= 0; --k) if (dd[k] != 0.0f) last = k;      // first done in the window
+        float acc = rr[last];
+        for (int k = last - 1; k >= 0; --k) acc = rr[k] + gamma * acc;
+        r[i] = acc; d[i] = last == n_step - 1 ? dd[n_step - 1] : 1.0f;
+    }
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -1347,20 +1361,28 @@ extern "C" int dqn_cnn_replay_size_host(const dqn_cnn_handle *h, int64_t *size, 
     return DQN_OK;
 }
 
-/* sample_batch's gather (replay_buffer.py:79-85) for given indices */
-extern "C" int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, uint8_t *s, int32_t *a, float *r, uint8_t *s2, float *d, void *stream) {
+/* sample_batch's gather (replay_buffer.py:79-85) for given indices. n_step = 1: the stored rows. n_step 2..8 (rows stored
+ * step-major, n_envs per step): the n-step transition that starts at each row -- (s, a, R, s' of the last step, done_n) */
+extern "C" int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, int32_t n_step, int32_t n_envs, float gamma,
+                                     uint8_t *s, int32_t *a, float *r, uint8_t *s2, float *d, void *stream) {
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(idx && s && a && r && s2 && d && B >= 1, "bad argument");
-    hipLaunchKernelGGL(k_cnn_gather, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, h->ring_s, h->ring_s2, h->ring_a, h->ring_r, h->ring_d, idx, B, h->ring_cap, s, s2, a, r, d);
+    CNN_REQ(n_step >= 1 && n_step <= 8 && (n_step == 1 || (n_envs >= 1 && h->ring_cap % n_envs == 0 && (long long)n_step * n_envs <= h->ring_cap)), "bad n_step / n_envs");
+    hipLaunchKernelGGL(k_cnn_gather, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, h->ring_s, h->ring_s2, h->ring_a, h->ring_r, h->ring_d, idx, B, h->ring_cap,
+                       n_step, n_step == 1 ? 0 : n_envs, gamma, s, s2, a, r, d);
     CNN_TRY(hipGetLastError());
     return DQN_OK;
 }
 
-/* Agent._step (q_agent.py:146-169) from the frame ring: gather the rows idx (sampled by the caller's PER tree), update with
- * the importance weights isw (optional), |delta| per sample into td_abs_out (optional) for the priority write-back */
-extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream) {
+/* Agent._step (q_agent.py:146-169) from the frame ring: gather the rows idx (sampled by the caller's PER tree; n-step
+ * transitions when n_step > 1, bootstrapped with gamma^n), update with the importance weights isw (optional), |delta| per
+ * sample into td_abs_out (optional) for the priority write-back */
+extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t n_step, int32_t n_envs, int32_t B,
+                                     float *td_abs_out, float *loss_host, void *stream) {
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(idx && B >= 1 && B <= h->max_batch, "bad argument");
-    int rc = dqn_cnn_replay_gather(h, idx, B, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
-    return cnn_update_impl(h, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, isw, gamma, B, td_abs_out, loss_host, stream);
+    int rc = dqn_cnn_replay_gather(h, idx, B, n_step, n_envs, gamma, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
+    float gn = gamma;
+    for (int k = 1; k < n_step; ++k) gn = gn * gamma;                  // gamma^n as n - 1 f32 products
+    return cnn_update_impl(h, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, isw, gn, B, td_abs_out, loss_host, stream);
 }

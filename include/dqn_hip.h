@@ -285,11 +285,15 @@ int dqn_cnn_replay_init(dqn_cnn_handle *h, int64_t capacity);
 int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
                        const float *d, int32_t n, int64_t *first_index, void *stream);
 int dqn_cnn_replay_size_host(const dqn_cnn_handle *h, int64_t *size, int64_t *counter);
-int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, uint8_t *s, int32_t *a, float *r, uint8_t *s2,
-                          float *d, void *stream);
-/* Agent._step from the frame ring: gather idx + dqn_cnn_update; td_abs_out (device, optional) = |delta| per sample */
-int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t B,
-                          float *td_abs_out, float *loss_host, void *stream);
+/* n_step = 1: the stored rows. n_step 2..8 with the rows stored step-major (n_envs rows per env step, capacity a multiple of
+ * n_envs): the n-step transition that STARTS at each row -- s and a of the row, R = r_0 + gamma (r_1 + ...) cut after the first done,
+ * s' of the last step, that done flag; sample only rows whose n - 1 successors are already in the ring. */
+int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int32_t B, int32_t n_step, int32_t n_envs, float gamma,
+                          uint8_t *s, int32_t *a, float *r, uint8_t *s2, float *d, void *stream);
+/* Agent._step from the frame ring: gather idx (n-step transitions when n_step > 1, bootstrapped with gamma^n) + dqn_cnn_update;
+ * td_abs_out (device, optional) = |delta| per sample */
+int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, const float *isw, float gamma, int32_t n_step, int32_t n_envs,
+                          int32_t B, float *td_abs_out, float *loss_host, void *stream);
 
 #ifdef __cplusplus
 }

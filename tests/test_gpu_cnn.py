@@ -349,3 +349,69 @@ def test_cnn_against_golden(dq):
     ref = g["grad64_strided"]
     assert np.abs(gr[::997] - ref).max() <= 1e-5 * np.abs(ref).max()
     e.close()
+
+
+def test_cnn_nstep_gather(dq):
+    """n-step returns from the frame ring (arithmetic of nstep_row / the MLP engine): rows are stored one env
+    step each, step-major; the transition that starts at row p is (s_p, a_p, R = r_0 + g (r_1 + g r_2) cut after the first done,
+    s' of the last of the n rows, done_n) -- against a numpy model on a wrapped ring, f32 Horner form, bit-exact"""
+    cap, n_envs, n, g = 32, 4, 3, np.float32(0.9)
+    e = dq.CnnEngine(num_actions=A, max_batch=16, precision="bf16")
+    e.replay_init(cap)
+    rng = np.random.default_rng(13)
+    S = np.zeros((cap, 84, 84, 4), np.uint8); S2 = np.zeros_like(S)
+    Aa = np.zeros(cap, np.int32); R = np.zeros(cap, np.float32); D = np.zeros(cap, np.float32)
+    steps = 11                                                     # 44 rows into 32: wrapped
+    for t in range(steps):
+        s = rng.integers(0, 256, (n_envs, 84, 84, 4), dtype=np.uint8); s2 = rng.integers(0, 256, (n_envs, 84, 84, 4), dtype=np.uint8)
+        a = rng.integers(0, A, n_envs).astype(np.int32); r = rng.standard_normal(n_envs).astype(np.float32); d = (rng.random(n_envs) < 0.35).astype(np.float32)
+        pos = (t * n_envs + np.arange(n_envs)) % cap
+        e.replay_add(s, a, r, s2, d)
+        S[pos], S2[pos], Aa[pos], R[pos], D[pos] = s, s2, a, r, d
+    # rows of the steps steps-n .. whose windows are complete and whose frames are still there: steps 3 .. 8
+    valid_steps = np.arange(steps - cap // n_envs, steps - n + 1)
+    idx = np.concatenate([(t * n_envs + np.arange(n_envs)) % cap for t in valid_steps]).astype(np.int32)[:16]
+    gs, ga, gr, gs2, gd = (host(x) for x in e.replay_gather(idx, n_step=n, n_envs=n_envs, gamma=float(g)))
+    wr, wd, wlast = np.zeros(idx.size, np.float32), np.zeros(idx.size, np.float32), np.zeros(idx.size, np.int64)
+    for i, p in enumerate(idx):
+        rows = [(p + k * n_envs) % cap for k in range(n)]
+        last = n - 1
+        for k in range(n - 2, -1, -1):
+            if D[rows[k]] != 0:
+                last = k
+        acc = R[rows[last]]
+        for k in range(last - 1, -1, -1):
+            acc = np.float32(R[rows[k]] + np.float32(g * acc))
+        wr[i], wd[i], wlast[i] = acc, (D[rows[n - 1]] if last == n - 1 else 1.0), rows[n - 1]
+    assert np.array_equal(ga, Aa[idx]) and np.array_equal(gr, wr) and np.array_equal(gd, wd)
+    assert np.array_equal(gs, S[idx]) and np.array_equal(gs2, S2[wlast])
+    assert 0 < wd.sum() < idx.size                                   # both truncated and full windows occurred
+    # n_step = 1 is the plain gather
+    g1 = [host(x) for x in e.replay_gather(idx)]
+    assert np.array_equal(g1[2], R[idx]) and np.array_equal(g1[4], D[idx]) and np.array_equal(g1[3], S2[idx])
+    e.close()
+
+
+def test_cnn_vector_agent_nstep(dq):
+    """the loop with n_step = 3: the PER index runs n - 1 vector steps behind the frame ring, overwritten rows leave the draw
+    until their successors exist, sampled rows always have complete windows"""
+    from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
+    ag = CnnVectorAgent(n_envs=8, num_actions=A, capacity=64, batch_size=16, precision="bf16", train_frequency=3, replace_frequency=2, lr=1e-3, seed=4, n_step=3, p_done=0.2)
+    ag.init_params(make_params(21))
+    seen = []
+    orig = ag.cnn.update_from_replay
+    def spy(idx, *a, **k):
+        seen.append((ag.env_steps, host(idx).copy()))
+        return orig(idx, *a, **k)
+    ag.cnn.update_from_replay = spy
+    losses = ag.training(6, want_loss=True)          # 4 + 18 = 22 vector steps: 176 rows into 64 -> the ring wraps twice
+    assert len(losses) == 6 and all(np.isfinite(l) for l in losses)
+    assert ag.index.replay_size()[1] == (ag.env_steps - 2) * 8 and ag.cnn.replay_size()[1] == ag.env_steps * 8
+    for steps_done, idx in seen:
+        # a sampled row's step must be one of the last capacity / n_envs steps, and at least n - 1 steps old
+        newest = steps_done - 1
+        step_of = lambda p: max(t for t in range(max(0, newest - 7), newest + 1) if (t * 8) % 64 <= p < (t * 8) % 64 + 8)
+        for p in idx:
+            assert newest - step_of(int(p)) >= 2, (steps_done, int(p))
+    assert ag.index.device_errors() == 0
+    ag.close()
