@@ -438,7 +438,7 @@ def cnn_lines(dq):
     from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
     ag = CnnVectorAgent(n_envs=Bc, num_actions=A_, capacity=1 << 14, batch_size=Bc, precision="bf16", train_frequency=4, seed=5, n_step=3)
     ag.init_params(torch.randn(ag.cnn.param_count) * 0.02)
-    ag.training(3)
+    ag.training(12)                    # past the first lap of the ring (32 vector steps): every kernel of the loop has run once
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     n_it = 10

@@ -74,7 +74,7 @@ class CnnVectorAgent:
             # successors do. So the PER index learns of step t - n + 1 when step t arrives (its own ring counter is n - 1 steps
             # behind: the same positions), and rows whose frames have just been overwritten are taken out of the draw until then.
             if self.env_steps * n >= self.cnn.capacity:
-                self.index.per_set(self._pos + first, self._zero_prio)
+                self.index.per_set_sorted(self._pos + first, self._zero_prio)
             if self.env_steps >= self.n_step - 1:
                 self.index.replay_add(*self._zeros)
         self.frames = nxt

@@ -51,6 +51,7 @@ SIGNATURES = {
     "dqn_per_update": [_P, _P, _P, _I32, _P],
     "dqn_per_set": [_P, _P, _P, _I32, _P],
     "dqn_per_update_sorted": [_P, _P, _P, _I32, _P],
+    "dqn_per_set_sorted": [_P, _P, _P, _I32, _P],
     "dqn_qnet_forward": [_P, C.c_int, _P, _I32, _P, _P, _P],
     "dqn_td_targets": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I32, _P, _P, _P, _P, _P],
     "dqn_q_targets": [_P, _P, _P, _P, _P, _P, _I32, _P, _P],

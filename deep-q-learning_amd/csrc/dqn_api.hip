@@ -426,14 +426,20 @@ extern "C" int dqn_per_update(dqn_handle *h, const int32_t *idx, const float *td
 extern "C" int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream) {
     return per_write(h, idx, prio, B, 0, stream);
 }
-extern "C" int dqn_per_update_sorted(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream) {
-    REQUIRE(h && idx && td_abs, "null argument");
+static int per_write_sorted(dqn_handle *h, const int32_t *idx, const float *val, int32_t B, int mode, void *stream) {
+    REQUIRE(h && idx && val, "null argument");
     if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
     REQUIRE(B >= 1, "B must be >= 1");
-    launch_per_write_sorted((hipStream_t)stream, h->st, h->tree, h->Ntree, h->L, idx, td_abs, B, 1,
+    launch_per_write_sorted((hipStream_t)stream, h->st, h->tree, h->Ntree, h->L, idx, val, B, mode,
                             h->cfg.per_alpha, h->cfg.per_eps);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
+}
+extern "C" int dqn_per_update_sorted(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream) {
+    return per_write_sorted(h, idx, td_abs, B, 1, stream);
+}
+extern "C" int dqn_per_set_sorted(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream) {
+    return per_write_sorted(h, idx, prio, B, 0, stream);
 }
 
 // ------------------------------------------------------------------------------ network

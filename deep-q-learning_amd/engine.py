@@ -237,6 +237,11 @@ class Engine:
         idx, td_abs = self.dev(idx, torch.int32), self.dev(td_abs, torch.float32)
         L.check(self.lib.dqn_per_update_sorted(self.h, _ptr(idx), _ptr(td_abs), idx.numel(), self._s()))
 
+    def per_set_sorted(self, idx, prio):
+        """as per_set, for non-decreasing idx"""
+        idx, prio = self.dev(idx, torch.int32), self.dev(prio, torch.float32)
+        L.check(self.lib.dqn_per_set_sorted(self.h, _ptr(idx), _ptr(prio), idx.numel(), self._s()))
+
     def per_set(self, idx, prio):
         idx, prio = self.dev(idx, torch.int32), self.dev(prio, torch.float32)
         L.check(self.lib.dqn_per_set(self.h, _ptr(idx), _ptr(prio), idx.numel(), self._s()))

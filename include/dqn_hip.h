@@ -137,6 +137,8 @@ int dqn_per_set(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B,
 /* same result as dqn_per_update for NON-DECREASING idx (what dqn_per_sample returns): spread over many
  * CUs, siblings and duplicates resolved between adjacent positions. Undefined for unsorted idx. */
 int dqn_per_update_sorted(dqn_handle *h, const int32_t *idx, const float *td_abs, int32_t B, void *stream);
+/* as dqn_per_set (raw priorities, e.g. 0 to take rows out of the draw), for non-decreasing idx: the many-CU write-back */
+int dqn_per_set_sorted(dqn_handle *h, const int32_t *idx, const float *prio, int32_t B, void *stream);
 
 /* Model.__call__ (LunarLander/dddqn.py:24-34): q[B,A]; feat (optional) = the H2
  * features of return_features=True (:32-33). */

@@ -882,3 +882,27 @@ def test_tree_invariant_under_replay_stress(dq):
                 assert bad.numel() == 0, (rep, bad[:8].flatten().tolist())
     assert e.opt_count() == 400
     e.close()
+
+
+def test_per_set_sorted_equals_per_set(dq):
+    """dqn_per_set_sorted (raw priorities through the many-CU sorted write-back) leaves the same tree as dqn_per_set, zeros
+    included (rows taken out of the draw), and a later draw never returns a zeroed row"""
+    L_ = 12; N = 1 << L_
+    rng = np.random.default_rng(5)
+    engs = [dq.Engine(dq.EngineConfig(obs_dim=4, hidden1=16, hidden2=16, num_actions=2, capacity=N, use_per=True, max_batch=256, seed=3)) for _ in range(2)]
+    s = rng.standard_normal((N, 4)).astype(np.float32)
+    for e in engs:
+        for k in range(0, N, 1024):
+            e.replay_add(s[k:k + 1024], np.zeros(1024, np.int32), np.zeros(1024, np.float32), s[k:k + 1024], np.zeros(1024, np.uint8))
+    idx = np.sort(rng.choice(N, 300, replace=False)).astype(np.int32)
+    prio = rng.uniform(0.0, 2.0, idx.size).astype(np.float32); prio[::3] = 0.0
+    engs[0].per_set(idx, prio); engs[1].per_set_sorted(idx, prio)
+    t0, t1 = (host(e.buffer(dq._lib.BUF_TREE)) for e in engs)
+    assert np.array_equal(t0, t1)
+    k = np.arange(1, N)
+    assert np.array_equal(t1[k], t1[2 * k] + t1[2 * k + 1])
+    zero_rows = set(idx[::3].tolist())
+    (_, _, _, _, _), got, _ = engs[1].per_sample(256, 0.4, 1, 0)
+    assert not (set(host(got).tolist()) & zero_rows)
+    for e in engs:
+        e.close()
