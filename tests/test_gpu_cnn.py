@@ -415,3 +415,34 @@ def test_cnn_vector_agent_nstep(dq):
             assert newest - step_of(int(p)) >= 2, (steps_done, int(p))
     assert ag.index.device_errors() == 0
     ag.close()
+
+
+def test_cnn_update_in_a_captured_graph(dq):
+    """dqn_cnn_update forks to the handle's side stream and joins by events: captured into a hipGraph (torch.cuda.graph) and
+    replayed it must do what the eager launches do -- same parameters after two steps, bit for bit"""
+    import torch
+    B = 8
+    rng = np.random.default_rng(17)
+    P = make_params(41)
+    s = torch.as_tensor(rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)).cuda(); s2 = torch.as_tensor(rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)).cuda()
+    a = torch.as_tensor(rng.integers(0, A, B).astype(np.int32)).cuda(); r = torch.as_tensor(rng.standard_normal(B).astype(np.float32)).cuda()
+    d = torch.as_tensor((rng.random(B) < 0.3).astype(np.float32)).cuda(); w = torch.as_tensor(rng.uniform(0.3, 1.0, B).astype(np.float32)).cuda()
+    eager, graphed = (dq.CnnEngine(num_actions=A, max_batch=8, precision="f32") for _ in range(2))
+    for e in (eager, graphed):
+        e.set_params(P); e.set_params(P, target=True); e.set_optimizer(lr=1e-3)
+    for _ in range(2):
+        eager.update(s, a, r, s2, d, w)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            graphed.update(s, a, r, s2, d, w)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(graphed.get_buffer("params")), P)        # capture launches nothing
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(host(graphed.get_buffer("params")), host(eager.get_buffer("params")))
+    assert np.array_equal(host(graphed.get_buffer("mu")), host(eager.get_buffer("mu")))
+    del g
+    eager.close(); graphed.close()
