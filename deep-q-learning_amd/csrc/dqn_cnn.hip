@@ -46,6 +46,7 @@ template <> struct CnnGeo<3> { static constexpr int IH = 1, IW = 1, IC = 3136, O
 //         V = 0 at B = 8192: those kernels are bound by staging (L2 -> registers -> LDS, 11 TB/s of L2 reads at B = 8192, the
 //         4x im2col expansion included), and four small workgroups per CU overlap it where one large one serialises it
 //         (128 x 64 tiles, two workgroups per CU: 123 -> 145 us for conv2, 61 -> 83 us for conv3 -- slower as well)
+//         and smaller ones at B = 512 (32 x 32 from 16 x 16 MFMA tiles: conv2 10.3 -> 12.6 us, conv3 8.2 -> 9.3 us): 64 x 64 is the optimum
 template <int L, int V> struct CnnTile;
 template <> struct CnnTile<0, 0> { static constexpr int MT = 32, WM = 4, WN = 1, TM = 1, TN = 1, R = 4; };
 template <> struct CnnTile<1, 0> { static constexpr int MT = 32, WM = 2, WN = 2, TM = 1, TN = 1, R = 4; };
