@@ -454,8 +454,13 @@ template <typename TC, int L> struct DwRows { static constexpr int MR = sizeof(T
 
 // f32: natural-order row images
 template <typename TR>
-__device__ __forceinline__ void commit_row_piece(float *dst, const TR &raw, const float *lut) {
-    float v[8]; piece_f32(raw, lut, v);
+__device__ __forceinline__ void commit_row_piece(float *dst, const TR &raw, const float *) {
+    float v[8];
+    if constexpr (__is_same(TR, uint2)) {      // conv1's dW multiplies the INTEGER pixels (exact in f32) and divides the sum by 255 in the reduction
+        const uint32_t w[2] = {raw.x, raw.y};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    } else piece_f32(raw, nullptr, v);
     *reinterpret_cast<float4 *>(dst) = float4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<float4 *>(dst + 4) = float4{v[4], v[5], v[6], v[7]};
 }
@@ -492,9 +497,8 @@ k_cnn_dw(int M, int rows_per_slice, const TI *__restrict__ in, const TC *__restr
     __shared__ __attribute__((aligned(16))) TC lA[LBUF * (TR ? KT * LSA : MR * LSA)];
     __shared__ __attribute__((aligned(16))) TC lB[LBUF * (TR ? NT * LSB : MR * LSB)];
     constexpr int ASZ = TR ? KT * LSA : MR * LSA, BSZ = TR ? NT * LSB : MR * LSB;
-    __shared__ float lut[(sizeof(TI) == 1 && sizeof(TC) == 4) ? 256 : 1];
+    const float *lut = nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wk = wave / WN, wn = wave % WN, hi = lane >> 5, c = lane & 31;
-    if constexpr (sizeof(TI) == 1 && sizeof(TC) == 4) { lut[tid] = __fdiv_rn((float)tid, 255.0f); __syncthreads(); }
     const int tile = blockIdx.x % (KTILES * NTILES), slice = blockIdx.x / (KTILES * NTILES);
     const int kt0 = (tile / NTILES) * KT, n0 = (tile % NTILES) * NT;
     const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
@@ -1214,7 +1218,7 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd, h->ev_dz[1], 0); }
     launch_dw<TC, TC, 1>(h, sd, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
     launch_bwd_data<TC, 1>(h, s, B);
-    launch_dw<uint8_t, TC, 0>(h, s, B, frames, (const TC *)h->dz[0], segs, nseg, sizeof(TC) == 2 ? 255.0f : 1.0f);   // bf16 mode multiplies integer pixels
+    launch_dw<uint8_t, TC, 0>(h, s, B, frames, (const TC *)h->dz[0], segs, nseg, 255.0f);      // the kernel multiplies integer pixels (both modes)
     if (h->side) { (void)hipEventRecord(h->ev_side, sd); (void)hipStreamWaitEvent(s, h->ev_side, 0); }
     long long total = 0;
     for (int i = 0; i < nseg; ++i) total += segs.s[i].units;
