@@ -229,20 +229,27 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TI *__restrict__ in2, int im
         multiply(buf);
         if constexpr (LBUF == 1) __syncthreads();
     }
+    // outputs first, then the (predicated) stores: with the bias add inside the row test every store block starts with a
+    // vmcnt(0) for the bias load -- which then waits for the PREVIOUS STORE (stores count in vmcnt on gfx9): 16 serial round trips
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + MT * (TN * wn + j) + c;
         const float bv = bias[n];
+        float o[TM][NACC];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < NACC; ++r) {
+                const float v = acc[i][j][r] + bv;
+                o[i][r] = v > 0.0f ? v : 0.0f;
+                asm volatile("" : "+v"(o[i][r]));                   // materialised here: nothing of the bias load is left for the store blocks
+            }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int mm = m0 + MT * (TM * wm + i) + (MT == 32 ? (r & 3) + 8 * (r >> 2) + 4 * hi : 4 * hi + r);
-                if (mm < M) {
-                    float v = acc[i][j][r] + bv;
-                    v = v > 0.0f ? v : 0.0f;
-                    out[(long long)mm * G::OC + n] = (TC)v;
-                }
+                if (mm < M) out[(long long)mm * G::OC + n] = (TC)o[i][r];
             }
     }
 }
@@ -428,10 +435,13 @@ k_cnn_bwd_data(int B, const TC *__restrict__ dz, const TC *__restrict__ wb, cons
             mfma_chunk<TC, MT>(lA + buf * (BM * LS) + (MT * wm + c) * LS, lB + buf * (BN * LS) + (MT * wn + c) * LS, hi, acc);
         }
     }
+    float o[16];                                                      // values first, stores after (see k_cnn_layer's epilogue)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[r] = (float)gate_raw[r] > 0.0f ? acc[r] : 0.0f; asm volatile("" : "+v"(o[r])); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mm = m0 + MT * wm + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (mm < M) out[out_off(r)] = (float)gate_raw[r] > 0.0f ? (TC)acc[r] : (TC)0.0f;
+        if (mm < M) out[out_off(r)] = (TC)o[r];
     }
 }
 
