@@ -623,6 +623,7 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
     // actor launch, or uniform replay): the row backward rides in the forward launch (pass-0 workgroups go on with it)
     const int grid_tiles = h->bf16 ? 2 * ((B + 31) / 32) : (B + 15) / 16;
     const bool fuse_rows = 3 * grid_tiles <= h->num_cus && (presampled || !h->cfg.use_per) && !h->no_handover;
+    if (fuse_rows) p[0].q = nullptr;        // the pass-0 workgroup keeps its Q rows in registers for the TD rule; nobody else reads them
     arm(h);
     L_fwd(h, st, p, 3, B, &sm, fuse_rows ? &g : nullptr);
     mark(h, st, fuse_rows ? "sample_fwd_x3_bwd" : "sample_fwd_x3");

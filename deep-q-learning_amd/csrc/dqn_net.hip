@@ -467,8 +467,19 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         } else {
             for (int a = 0; a < m.A; ++a) qrow[a] = (hr[0] + hr[1 + a]) - mean;
         }
-        if (FUSE && blockIdx.y != 0) {
-            for (int a = 0; a < m.A; ++a) __hip_atomic_store(&ps.q[(long long)(row0 + tid) * m.A + a], qrow[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (FUSE) {
+            if (blockIdx.y != 0) {
+                // the partners' Q rows, all stores of a row back to back: written as a runtime loop the compiler puts a vmcnt(0)
+                // in front of every store, i.e. each waits for the acknowledgement of the one before (stores count in vmcnt)
+#pragma unroll
+                for (int a = 0; a < 15; ++a) asm volatile("" : "+v"(qrow[a]));
+#pragma unroll
+                for (int a = 0; a < 15; ++a)
+                    if (a < m.A) __hip_atomic_store(&ps.q[(long long)(row0 + tid) * m.A + a], qrow[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (ps.q) {
+#pragma unroll
+                for (int a = 0; a < 15; ++a) if (a < m.A) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
+            }
         } else if (ps.q) for (int a = 0; a < m.A; ++a) ps.q[(long long)(row0 + tid) * m.A + a] = qrow[a];
         if (ps.act_out) {
             const float eps = ps.act_state ? ps.act_state->epsilon : ps.act_eps;
@@ -525,7 +536,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                     ntr[k2] = k2 < A ? __hip_atomic_load(&g.nt[(long long)irow * A + k2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
                 }
                 float w = 1.0f;
-                if (g.w_raw) { w = __fdiv_rn(wi, wmax); if (g.isw_out) g.isw_out[irow] = w; }
+                if (g.w_raw) w = __fdiv_rn(wi, wmax);
                 const float invB = __fdiv_rn(1.0f, (float)B);
                 float best = nqr[0], nt_star = ntr[0], q_a = qrow[0];   // :55 argmax, first max wins; q[action]
 #pragma unroll
@@ -537,9 +548,13 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
                 const float t1 = g.gamma * nt_star;                      // :58, quirk Q3: (1-d) covers -q too
                 const float t2 = t1 - q_a;
                 const float t3 = (1.0f - di) * t2;
-                const float delta = row_r + t3;
+                float delta = row_r + t3, dabs = fabsf(delta);
+                // the three per-row outputs, values first: each `if (ptr) store` block otherwise opens with a vmcnt(0) (for the
+                // loads delta hangs on) that waits for the store of the block before it
+                asm volatile("" : "+v"(delta), "+v"(dabs), "+v"(w));
+                if (g.w_raw && g.isw_out) g.isw_out[irow] = w;
                 if (g.td) g.td[irow] = delta;
-                if (g.td_abs) g.td_abs[irow] = fabsf(delta);
+                if (g.td_abs) g.td_abs[irow] = dabs;
                 float gk[AMAX], gsum = 0.0f;
 #pragma unroll
                 for (int k2 = 0; k2 < AMAX; ++k2) {
