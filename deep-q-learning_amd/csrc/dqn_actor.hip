@@ -383,6 +383,10 @@ k_actor(NetDims m, ActorArgs g) {
         f32x4 w2q[BF ? 1 : 4 * KB], w2q8[BF ? 2 * KB : 1];
         constexpr int N1 = BF ? 0 : (4 * KB < 32 ? 4 * KB : 32);   // first part of the slab; the rest follows the small operands
         const int vw2 = (int)(cc2 * 16u);
+        // An actor workgroup has no memory operation in flight here, but the compiler's bookkeeping merges in the side roles' stores
+        // (same registers) and put a vmcnt(0) after the THIRD slab request below: the rest of the slab waited for a round trip.
+        // A wait it can see costs nothing now and clears that bookkeeping (vmcnt 0, expcnt 7, lgkmcnt 15).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if constexpr (BF) {
 #pragma unroll
             for (int u = 0; u < 2 * KB; ++u) {           // (as below: the later half straight to accumulation VGPRs -- an "=v" result the
