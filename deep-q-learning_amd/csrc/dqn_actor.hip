@@ -475,7 +475,7 @@ k_actor(NetDims m, ActorArgs g) {
         if (tid == 0) {
             unsigned int one = 1u;
             asm volatile("" : "+s"(one) : "s"(c0), "s"(ec), "s"(hs0));
-            ticket = atomicAdd(&e.st->arrive, one);
+            ticket = ticket_take_async(&e.st->arrive, one);
         }
         asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
                                                  // where a full vmcnt wait would also wait for the previous step's ring stores)
@@ -867,7 +867,8 @@ k_actor(NetDims m, ActorArgs g) {
     // workgroup that reaches this barrier has finished reading them)
     LDS_BARRIER();
     if (tid == 0) {
-        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue)
+        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue,
+        else ticket_wait(ticket);                                                                 //  asynchronously: dqn_device.h)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
@@ -999,7 +1000,7 @@ k_actor16(NetDims m, ActorArgs g) {
             if (tile == wg && tid == 0) {                                    // arrival ticket, early (see k_actor): every wave has c0 / ec
                 unsigned int one = 1u;
                 asm volatile("" : "+s"(one) : "s"(c0), "s"(ec));
-                ticket = atomicAdd(&e.st->arrive, one);
+                ticket = ticket_take_async(&e.st->arrive, one);
             }
 
             for (int t = 0, tc = 0; t < g.T; ++t, tc = tc + 1 == g.TC ? 0 : tc + 1) {   // tc = t % TC without the division
@@ -1152,7 +1153,8 @@ k_actor16(NetDims m, ActorArgs g) {
     }
     LDS_BARRIER();
     if (tid == 0) {
-        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue)
+        if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue,
+        else ticket_wait(ticket);                                                                 //  asynchronously: dqn_device.h)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65

@@ -126,6 +126,17 @@ __device__ __forceinline__ float pow_det(float x, float a) { return exp2_det(a *
 // ------------------------------------------------------------------ diagnostic stamps
 // -DDQN_STAMPS builds (tools only, never shipped): thread 0 of block (0,0) records
 // (s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks) at named points of a kernel.
+// A returning atomic add whose result is NOT waited for here: `atomicAdd` goes through the compiler's atomic optimiser (one
+// lane adds, s_waitcnt vmcnt(0), v_readfirstlane broadcast), i.e. the caller stalls for the whole round trip on the spot --
+// which defeated the "ticket taken early, looked at at the end" pattern of the commit blocks (seen in the ISA, r02). The
+// result register is valid only after ticket_wait() (or any later full vmcnt wait).
+__device__ __forceinline__ unsigned int ticket_take_async(unsigned int *p, unsigned int v) {
+    unsigned int r;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(r) : "v"(p), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ void ticket_wait(unsigned int &t) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(t) :: "memory"); }
+
 #ifdef DQN_STAMPS
 extern __device__ unsigned long long g_stamps[8][64][2];   // [kernel][slot][clock kind]
 #define STAMP(K, S)                                                                         \
@@ -134,4 +145,5 @@ extern __device__ unsigned long long g_stamps[8][64][2];   // [kernel][slot][clo
              g_stamps[K][S][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(K, S) do { } while (0)
+
 #endif
