@@ -472,13 +472,14 @@ k_actor(NetDims m, ActorArgs g) {
         // The commit at the end of the launch needs "every workgroup has READ the counters", not "has finished": an actor
         // workgroup takes its ticket here -- every wave is past the barrier above, i.e. has c0 / ec (/ hs0) in registers --
         // and looks at it at the end, so the returning atomic's round trip is not the tail of the launch.
+        asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
+                                                 // where a full vmcnt wait would also wait for the previous step's ring stores --
+                                                 // and BEFORE the ticket below, whose round trip the same wait would sit out)
         if (tid == 0) {
             unsigned int one = 1u;
             asm volatile("" : "+s"(one) : "s"(c0), "s"(ec), "s"(hs0));
             ticket = ticket_take_async(&e.st->arrive, one);
         }
-        asm volatile("" : "+v"(eps));            // (compiler-tracked load: waited for HERE, not by the pin inside the step loop,
-                                                 // where a full vmcnt wait would also wait for the previous step's ring stores)
         // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
