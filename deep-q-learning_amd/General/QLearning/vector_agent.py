@@ -44,11 +44,17 @@ class VectorAgent:
         engine.sync_target()
         self.updates = 0
 
-    def inject(self, gamma, epsilon, epsilon_decay_rate, min_epsilon, replace_frequency, batch_size, train_frequency):
+    def inject(self, gamma, epsilon, epsilon_decay_rate, min_epsilon, replace_frequency, batch_size, train_frequency,
+               rebuild_closures=False):
         """ParamAgent.inject (General/QLearning/hyperparameter_optimization.py:76-91) for the device-resident loop: the seven
-        searched hyper-parameters are replaced between two training runs. gamma is baked into the captured launches
-        (dqn_set_gamma drops them), epsilon lives on the device, batch size / train frequency select the loop graph."""
-        self.e.set_gamma(float(gamma))
+        searched hyper-parameters are replaced between two training runs; epsilon lives on the device, batch size / train
+        frequency select the loop graph. gamma: the reference only rebinds `_gamma` (:84) -- its jitted q-target closure
+        (q_agent.py:111, built once in the constructor) keeps the constructor's discount, so an injected gamma has NO effect
+        on training there. Same here by default, exactly as the `ParamAgent` mirror; `rebuild_closures=True` (not in the
+        reference) applies it: gamma is baked into the captured launches and dqn_set_gamma drops and re-captures them."""
+        self.gamma = float(gamma)                                            # :84 (an attribute, as in the reference)
+        if rebuild_closures:
+            self.e.set_gamma(self.gamma)
         self.epsilon, self.decay, self.min_eps = float(epsilon), float(epsilon_decay_rate), float(min_epsilon)
         self.e.set_epsilon(self.epsilon)
         self.replace_frequency, self.train_frequency = int(replace_frequency), int(train_frequency)

@@ -478,7 +478,7 @@ k_actor(NetDims m, ActorArgs g) {
         if (tid == 0) {
             unsigned int one = 1u;
             asm volatile("" : "+s"(one) : "s"(c0), "s"(ec), "s"(hs0));
-            ticket = ticket_take_async(&e.st->arrive, one);
+            ticket = ticket_take_early(&e.st->arrive, one);
         }
         // heads: lwh[c][k], c = 0: value column (dddqn.py:29), c = 1..A: advantage columns (:30)
 #pragma unroll
@@ -869,7 +869,7 @@ k_actor(NetDims m, ActorArgs g) {
     LDS_BARRIER();
     if (tid == 0) {
         if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue,
-        else ticket_wait(ticket);                                                                 //  asynchronously: dqn_device.h)
+                                                                                                  //  ticket_take_early, dqn_device.h)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65
@@ -1001,7 +1001,7 @@ k_actor16(NetDims m, ActorArgs g) {
             if (tile == wg && tid == 0) {                                    // arrival ticket, early (see k_actor): every wave has c0 / ec
                 unsigned int one = 1u;
                 asm volatile("" : "+s"(one) : "s"(c0), "s"(ec));
-                ticket = ticket_take_async(&e.st->arrive, one);
+                ticket = ticket_take_early(&e.st->arrive, one);
             }
 
             for (int t = 0, tc = 0; t < g.T; ++t, tc = tc + 1 == g.TC ? 0 : tc + 1) {   // tc = t % TC without the division
@@ -1155,7 +1155,7 @@ k_actor16(NetDims m, ActorArgs g) {
     LDS_BARRIER();
     if (tid == 0) {
         if (role != 1) ticket = atomicAdd(&e.st->arrive, 1u);                                     // (actor workgroups: taken in the prologue,
-        else ticket_wait(ticket);                                                                 //  asynchronously: dqn_device.h)
+                                                                                                  //  ticket_take_early, dqn_device.h)
         if (ticket == total_wgs - 1u) {
             e.st->ring_counter = c1;                                                              // replay_buffer.py:64
             e.st->size = (long long)(c1 < (unsigned long long)e.cap ? c1 : (unsigned long long)e.cap);   // :65

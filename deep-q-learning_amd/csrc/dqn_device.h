@@ -123,20 +123,25 @@ __device__ __forceinline__ float exp2_det(float y) {
 
 __device__ __forceinline__ float pow_det(float x, float a) { return exp2_det(a * log2_det(x)); }
 
+// Arrival ticket of the "last workgroup commits" blocks, taken early and looked at at the end of the kernel. `atomicAdd` on
+// a uniform address goes through the compiler's atomic optimiser (one lane adds, s_waitcnt vmcnt(0), v_readfirstlane
+// broadcast): the caller stalls for the whole round trip where the ticket is TAKEN (seen in the ISA, r02). Here the address
+// is made opaque (a "v" asm output is a divergent value for the optimiser), so the one calling lane issues a plain returning
+// `global_atomic_add_u32 ... sc0` whose result is an ordinary compiler-tracked VGPR: the compiler places the vmcnt wait in
+// front of the first instruction that reads it. (r02's inline-asm atomic handed the compiler a result register that was not
+// valid yet; under register pressure it was copied to an AGPR at once -- a stale ticket -- and the VGPR reused while the
+// atomic was in flight: ADVICE r02, tools/isa_scan.py now rejects any such pattern.)
+__device__ __forceinline__ unsigned int ticket_take_early(unsigned int *p, unsigned int v) {
+    // (as a GLOBAL pointer: an opaque generic pointer becomes a flat atomic, which also counts in lgkmcnt -- the next LDS
+    // barrier would sit out its round trip)
+    __attribute__((address_space(1))) unsigned int *g = (__attribute__((address_space(1))) unsigned int *)p;
+    asm volatile("" : "+v"(g));
+    return __hip_atomic_fetch_add(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ diagnostic stamps
 // -DDQN_STAMPS builds (tools only, never shipped): thread 0 of block (0,0) records
 // (s_memtime shader-clock ticks, s_memrealtime 100 MHz ticks) at named points of a kernel.
-// A returning atomic add whose result is NOT waited for here: `atomicAdd` goes through the compiler's atomic optimiser (one
-// lane adds, s_waitcnt vmcnt(0), v_readfirstlane broadcast), i.e. the caller stalls for the whole round trip on the spot --
-// which defeated the "ticket taken early, looked at at the end" pattern of the commit blocks (seen in the ISA, r02). The
-// result register is valid only after ticket_wait() (or any later full vmcnt wait).
-__device__ __forceinline__ unsigned int ticket_take_async(unsigned int *p, unsigned int v) {
-    unsigned int r;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(r) : "v"(p), "v"(v) : "memory");
-    return r;
-}
-__device__ __forceinline__ void ticket_wait(unsigned int &t) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(t) :: "memory"); }
-
 #ifdef DQN_STAMPS
 extern __device__ unsigned long long g_stamps[8][64][2];   // [kernel][slot][clock kind]
 #define STAMP(K, S)                                                                         \

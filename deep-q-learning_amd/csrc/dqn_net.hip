@@ -1014,7 +1014,7 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     if (ad.P && tid == 0) {
         unsigned int one = 1u;
         asm volatile("" : "+v"(one) : "v"(co.c1), "v"(co.c2), "v"(co.neglr));
-        ticket = ticket_take_async(&st->arrive, one);
+        ticket = ticket_take_early(&st->arrive, one);
     }
     // reduce the four K-slices in wave order (fixed => deterministic), then write / apply
     {
@@ -1070,7 +1070,6 @@ k_dw(NetDims m, const float *__restrict__ px, const float *__restrict__ ph1, con
     if (ad.P) {
         // commit the optimizer counters once every block has read them: the block that drew the last ticket (tickets are
         // taken after the operand waits, above) writes them
-        if (tid == 0) ticket_wait(ticket);
         if (tid == 0 && ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
     }
     STAMP(6, 3);

@@ -711,7 +711,7 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
     if (ad.P && tid == 0) {
         unsigned int one = 1u;
         asm volatile("" : "+v"(one) : "v"(co.c1), "v"(co.c2), "v"(co.neglr));
-        ticket = ticket_take_async(&st->arrive, one);
+        ticket = ticket_take_early(&st->arrive, one);
     }
     {
         const int rr = tid >> 4, c = tid & 15;
@@ -756,7 +756,6 @@ k_dw16(NetDims m, Dims16 d, const __bf16 *__restrict__ px, const __bf16 *__restr
         }
     }
     if (ad.P) {
-        if (tid == 0) ticket_wait(ticket);
         if (tid == 0 && ticket == (unsigned)tiles - 1u) { st->b1pow = b1pow; st->b2pow = b2pow; st->adam_count += 1; st->arrive = 0; }
     }
 }

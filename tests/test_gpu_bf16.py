@@ -195,3 +195,29 @@ def test_bf16_actor_chain_agrees_with_the_bf16_forward(dq):
     assert np.array_equal(acts, host(e.buffer(dq._lib.BUF_ACTIONS, torch.int32))[:n])      # the ring got the same actions
     e.close()
 
+
+
+@pytest.mark.parametrize("n_step,per", [(1, False), (3, False), (1, True)])
+def test_bf16_actor_counters_advance_without_per(dq, n_step, per):
+    """with uniform replay (no tree / sampler workgroups in the actor launch) the counter commit at the
+    end of k_actor hangs on an ACTOR workgroup drawing the last arrival ticket. The bf16 / H1 > 128 instantiations once read
+    a stale ticket there (an inline-asm atomic whose result register the compiler copied before it had arrived): ring and
+    env counters never advanced. Ring counter, size and the policy stream's env counter must move by T*n / T per launch."""
+    import torch
+    dims = (8, 256, 256, 4)
+    n, T, N = 256, 4, 1 << 12
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=64, seed=3, n_step=n_step)
+    e.set_params(rand_params(dims, 7))
+    obs = np.random.default_rng(8).standard_normal((n, dims[0])).astype(np.float32)
+    e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
+    warm = n_step - 1                                            # the first n_step - 1 vector steps only fill the history
+    with torch.cuda.stream(e.stream):
+        for k in range(1, 8):
+            e.actor_steps(T)
+            e.stream.synchronize()
+            filed = (k * T - warm) * n
+            assert e.replay_size() == (min(filed, N), filed), (k, e.replay_size())
+    first = host(e.buffer(dq._lib.BUF_OBSERVATIONS).view(N, dims[0]))
+    assert np.isfinite(first).all() and np.abs(first).max() > 0
+    assert e.device_errors() == 0
+    e.close()

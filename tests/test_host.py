@@ -269,3 +269,63 @@ def test_cnn_oracle_reproduces_golden():
     for n, s_, a_ in zip(mk.LEAVES, g["leaf_sums"], g["leaf_abs"]):
         assert np.isclose(g64[o:o + n].sum(), s_, rtol=1e-9, atol=1e-13) and np.isclose(np.abs(g64[o:o + n]).sum(), a_, rtol=1e-10)
         o += n
+
+
+def test_isa_scan_flags_inflight_atomic_results_and_sources_have_none():
+    """a returning atomic written as inline asm hands the compiler a result register that is not valid until
+    the atomic returns. tools/isa_scan.py must flag a destination VGPR touched before the next `s_waitcnt vmcnt(0)` (the
+    two snippets are the shape of the r02 miscompile and of its fix), and the kernels must not contain such an atomic at
+    all (the tickets are compiler-tracked now: ticket_take_early, csrc/dqn_device.h). `make -C csrc check` runs the scan
+    over the real ISA (2 min of hipcc; not part of this suite)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    bad = """
+	;;#ASMSTART
+	global_atomic_add v82, v[86:87], v82, off sc0
+	;;#ASMEND
+	v_accvgpr_write_b32 a74, v82
+	v_bfe_u32 v82, v114, 4, 2
+	s_waitcnt vmcnt(0)
+	v_mov_b32 v1, v82
+""".split("\n")
+    got = isa_scan.inflight_atomic_hazards(bad)
+    assert len(got) == 2 and "v_accvgpr_write_b32" in got[0][1] and "v_bfe_u32" in got[1][1]
+    in_range = "\t;;#ASMSTART\n\tglobal_atomic_add v10, v[2:3], v4, off sc0\n\t;;#ASMEND\n\tglobal_load_dwordx4 v[8:11], v[2:3], off\n".split("\n")
+    assert len(isa_scan.inflight_atomic_hazards(in_range)) == 1
+    good = """
+	;;#ASMSTART
+	global_atomic_add v82, v[86:87], v82, off sc0
+	;;#ASMEND
+	v_mov_b32 v83, v84
+	s_waitcnt vmcnt(0)
+	v_accvgpr_write_b32 a74, v82
+	global_atomic_add v5, v[86:87], v7, off sc0
+	s_waitcnt vmcnt(0)
+	v_mov_b32 v1, v5
+""".split("\n")
+    assert isa_scan.inflight_atomic_hazards(good) == []                 # waited for; compiler-issued atomics are tracked
+    csrc = os.path.join(ROOT, "deep-q-learning_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            for m in re.finditer(r"asm\s+volatile\s*\(\s*\"[^;]*?_atomic_[^;]*?;", open(os.path.join(csrc, f)).read(), re.S):
+                assert not re.search(r"\b(sc0|glc)\b", m.group(0)), (f, m.group(0)[:120])
+
+
+def test_vector_agent_inject_gamma_semantics_match_param_agent():
+    """the two mirrors of ParamAgent.inject (hyperparameter_optimization.py:76-91) agree -- an injected gamma is
+    an attribute only (the reference's jitted closure keeps the constructor's), unless rebuild_closures=True is asked for."""
+    from deep_q_learning_amd.General.QLearning.vector_agent import VectorAgent
+
+    class Eng:
+        class cfg: max_batch = 64
+        def __init__(self): self.gammas, self.eps = [], []
+        def set_gamma(self, g): self.gammas.append(g)
+        def set_epsilon(self, x): self.eps.append(x)
+    a = VectorAgent.__new__(VectorAgent)
+    a.e = Eng()
+    a.inject(0.95, 0.8, 0.97, 0.05, 30, 48, 3)
+    assert a.e.gammas == [] and a.gamma == 0.95 and a.e.eps == [0.8] and (a.B, a.train_frequency, a.replace_frequency) == (48, 3, 30)
+    a.inject(0.9, 0.8, 0.97, 0.05, 30, 48, 3, rebuild_closures=True)
+    assert a.e.gammas == [0.9]
+    with pytest.raises(ValueError):
+        a.inject(0.9, 0.8, 0.97, 0.05, 30, 65, 3)

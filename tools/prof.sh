@@ -4,7 +4,7 @@
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --profile-steps 5 "$@" > $GRAFT_REPO_ROOT/gpurun_out/bench_$tag.json 2> $GRAFT_REPO_ROOT/gpurun_out/bench_$tag.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --profile-steps 5 "$@" > $GRAFT_REPO_ROOT/gpurun_out/bench_$tag.json 2> $GRAFT_REPO_ROOT/gpurun_out/bench_$tag.err
 echo "rc=$?"
 python3 - "$out" "$GRAFT_REPO_ROOT/gpurun_out/bench_$tag.json" <<'PY'
 import csv, glob, json, sys

@@ -4,7 +4,7 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-steps 2 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c.err
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c.err
   echo "$c rc=$?"
 done
 python3 - "$GRAFT_REPO_ROOT/gpurun_out" "$tag" <<'PY'

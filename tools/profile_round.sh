@@ -5,7 +5,6 @@
 #   per-kernel medians of the CNN forward / update (kernel trace); batch sweeps.
 tag=$1
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out
-sed -i 's/--no-cpu-baseline --profile-steps 5/--no-cpu-baseline --no-secondary --profile-steps 5/; s/--steps 200 --warmup 20 --no-cpu-baseline --profile-steps 2/--steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2/' $R/tools/prof.sh $R/tools/prof_pmc.sh
 bash $R/tools/prof.sh $tag --steps 400 --warmup 40 2>&1 | tail -12
 bash $R/tools/prof_pmc.sh $tag 2>&1 | tail -8
 bash $R/tools/prof_pmc_sample.sh $tag 2>&1 | tail -7
