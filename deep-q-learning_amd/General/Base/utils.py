@@ -1,6 +1,8 @@
 """Persistence helpers with the reference's names (General/Base/utils.py:21-40). The reference pickles jax
 DeviceArrays; this build writes the same dict-of-dicts (haiku names) and optimizer state as plain arrays in
-`<dir>/params.npz` / `<dir>/opt_state.npz` -- data only, loadable with numpy.load(allow_pickle=False)."""
+`<dir>/params.npz` / `<dir>/opt_state.npz` -- data only, loadable with numpy.load(allow_pickle=False). A directory that holds
+the REFERENCE's `params.pickle` / `opt_state.pickle` instead (e.g. its Test/lunar_lander/) is read token by token, without
+unpickling (pickle_tokens.py): `generate_loading` resumes from a reference checkpoint."""
 from __future__ import annotations
 
 import os
@@ -49,6 +51,15 @@ def generate_loading(directory, device=None):
                 mod, leaf = key[len(prefix):].split("|")
                 out.setdefault(mod, {})[leaf] = torch.as_tensor(z[key])
             return out
+        if not os.path.exists(os.path.join(directory, "params.npz")) and os.path.exists(os.path.join(directory, "params.pickle")):
+            from .pickle_tokens import read_adam_state, read_haiku_params
+            as_t = lambda t: {m: {k: torch.as_tensor(v) for k, v in lv.items()} for m, lv in t.items()}   # noqa: E731
+            p = as_t(read_haiku_params(os.path.join(directory, "params.pickle")))
+            dims = dims_of(p)
+            params = unflatten(flatten(p).to(dev), dims)
+            count, mu, nu, n_empty = read_adam_state(os.path.join(directory, "opt_state.pickle"))
+            adam = ScaleByAdamState(count, unflatten(flatten(as_t(mu)).to(dev), dims), unflatten(flatten(as_t(nu)).to(dev), dims))
+            return params, (adam,) + tuple(EmptyState() for _ in range(n_empty))
         with np.load(os.path.join(directory, "params.npz"), allow_pickle=False) as z:
             p = tree(z, "")
         dims = dims_of(p)

@@ -2,9 +2,10 @@
 """Generates tests/golden/*.npz from the CPU oracle (numpy f64 restatement, cross-checked against the plain-C
 one and PyTorch autograd in tests/test_oracle.py). Run from the repo root:  python tests/golden/make_golden.py
 
-PARITY UNPINNED: the reference holds no known-answer vectors and its pickled fixture is refused by the safe
-loader, so these vectors pin the build against ITS OWN oracle (regression), not against the reference's
-outputs. Fixtures are data only (inputs + expected outputs)."""
+PARITY UNPINNED: the reference holds no known-answer vectors, so these vectors pin the build against ITS OWN oracle
+(regression), not against the reference's outputs. The one fixture the reference does hold -- its initial parameters and
+zero optimizer state, Test/lunar_lander/*.pickle -- is the START of `cfg1_B64_refinit.npz` (r03): ref_init_params.npz, read
+out of the pickles token by token by extract_ref_init.py (no unpickling). Fixtures are data only (inputs + expected outputs)."""
 import os
 import sys
 
@@ -19,11 +20,21 @@ from test_oracle import CFGS, make_batch  # noqa: E402
 SUB = {"cfg1": 1, "cfg2": 23, "cfg3": 1}       # cfg2 keeps every 23rd element of P-sized outputs (+ checksums)
 
 
-def one(name, B, seed):
+def ref_init_flat():
+    """the reference's own initial parameters (Test/lunar_lander/params.pickle) in the flat haiku leaf order w b w b ..."""
+    z = np.load(os.path.join(HERE, "ref_init_params.npz"), allow_pickle=False)
+    return np.concatenate([z[f"model/~/linear{sfx}/{leaf}"].reshape(-1) for sfx in ("", "_1", "_2", "_3") for leaf in ("w", "b")]).astype(np.float32)
+
+
+def one(name, B, seed, ref_init=False):
     dims = CFGS[name]
-    P = onp.init_params(dims, seed)
-    P = (P + 0.05 * np.random.default_rng(seed + 100).standard_normal(P.size)).astype(np.float32)
-    Pt = onp.init_params(dims, seed + 1)
+    if ref_init:                              # Agent.__init__: target_params = params (q_agent.py:88-91)
+        P = ref_init_flat(); Pt = P.copy()
+        assert P.size == onp.param_count(*dims)
+    else:
+        P = onp.init_params(dims, seed)
+        P = (P + 0.05 * np.random.default_rng(seed + 100).standard_normal(P.size)).astype(np.float32)
+        Pt = onp.init_params(dims, seed + 1)
     s, a, r, s2, d = make_batch(dims, B, seed + 2)
     r = np.clip(r, -3, 3) if seed % 2 else r
     full = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64, full=True)
@@ -70,6 +81,11 @@ def per_case(L, n_add, B, seed):
 
 
 def main():
+    if "--ref-init-only" in sys.argv or "--all" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "cfg1_B64_refinit.npz"), **one("cfg1", 64, 6, ref_init=True))
+        print("wrote cfg1 64 from the reference's initial parameters")
+        if "--all" not in sys.argv:
+            return
     for name, B, seed in (("cfg1", 64, 0), ("cfg1", 1024, 1), ("cfg2", 64, 2), ("cfg2", 1024, 3), ("cfg3", 64, 4), ("cfg3", 1024, 5)):
         np.savez_compressed(os.path.join(HERE, f"{name}_B{B}_seed{seed}.npz"), **one(name, B, seed))
         print("wrote", name, B, seed)

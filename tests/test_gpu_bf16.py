@@ -205,14 +205,14 @@ def test_bf16_actor_counters_advance_without_per(dq, n_step, per):
     env counters never advanced. Ring counter, size and the policy stream's env counter must move by T*n / T per launch."""
     import torch
     dims = (8, 256, 256, 4)
-    n, T, N = 256, 4, 1 << 12
-    e = mk(dq, dims, capacity=N, use_per=per, max_batch=64, seed=3, n_step=n_step)
+    n, T, N = 256, 4, 1 << 14
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=n, seed=3, n_step=n_step)
     e.set_params(rand_params(dims, 7))
     obs = np.random.default_rng(8).standard_normal((n, dims[0])).astype(np.float32)
     e.env_reset(obs, p_done=0.05); e.set_epsilon(0.2)
     warm = n_step - 1                                            # the first n_step - 1 vector steps only fill the history
     with torch.cuda.stream(e.stream):
-        for k in range(1, 8):
+        for k in range(1, 20):
             e.actor_steps(T)
             e.stream.synchronize()
             filed = (k * T - warm) * n

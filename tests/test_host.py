@@ -329,3 +329,87 @@ def test_vector_agent_inject_gamma_semantics_match_param_agent():
     assert a.e.gammas == [0.9]
     with pytest.raises(ValueError):
         a.inject(0.9, 0.8, 0.97, 0.05, 30, 65, 3)
+
+
+# ------------------------------------------------- the reference's pickled fixture, read without unpickling
+class ScaleByAdamState(__import__("typing").NamedTuple):       # the shape of optax's state classes, for the file the test writes
+    count: object
+    mu: object
+    nu: object
+
+
+class EmptyState(__import__("typing").NamedTuple):
+    pass
+
+
+def test_pickle_token_reader_on_own_files(tmp_path):
+    """General/Base/pickle_tokens.py on pickles THIS test writes (protocol 4, numpy arrays in a haiku-shaped dict, and an
+    adam-shaped state: count, mu leaves, nu leaves): keys, shapes and bytes come back exactly, and generate_loading
+    (utils.py:32-40) resumes from such a directory. Nothing is unpickled on the read side."""
+    import pickle
+    from deep_q_learning_amd.General.Base import pickle_tokens as pt
+    from deep_q_learning_amd.General.Base.utils import generate_loading
+    from deep_q_learning_amd._tree import NAMES, shapes
+    dims = (9, 32, 64, 4)
+    rng = np.random.default_rng(0)
+    tree = {}
+    for mod, leaf, shp in shapes(dims):
+        tree.setdefault(mod, {})[leaf] = rng.standard_normal(shp).astype(np.float32)
+    mu = {m: {k: rng.standard_normal(tree[m][k].shape).astype(np.float32) for k in ("b", "w")} for m in NAMES}   # jax order: b, w
+    nu = {m: {k: np.abs(rng.standard_normal(tree[m][k].shape)).astype(np.float32) for k in ("b", "w")} for m in NAMES}
+    with open(tmp_path / "params.pickle", "wb") as f:
+        pickle.dump(tree, f, protocol=4)
+    with open(tmp_path / "opt_state.pickle", "wb") as f:
+        pickle.dump((ScaleByAdamState(np.array(7, np.int32), mu, nu), EmptyState(), EmptyState()), f, protocol=4)
+    got = pt.read_haiku_params(str(tmp_path / "params.pickle"))
+    assert list(got) == list(NAMES)
+    for m in NAMES:
+        for k in ("w", "b"):
+            assert got[m][k].dtype == np.float32 and np.array_equal(got[m][k], tree[m][k])
+    count, gmu, gnu, n_empty = pt.read_adam_state(str(tmp_path / "opt_state.pickle"))
+    assert count == 7 and n_empty == 2
+    assert all(np.array_equal(gmu[m][k], mu[m][k]) and np.array_equal(gnu[m][k], nu[m][k]) for m in NAMES for k in ("w", "b"))
+    params, st = generate_loading(str(tmp_path), device=torch.device("cpu"))()
+    assert params["model/~/linear_1"]["w"].shape == (32, 64) and st[0].count == 7 and len(st) == 3
+    assert np.array_equal(params["model/~/linear_3"]["w"].numpy(), tree["model/~/linear_3"]["w"])
+    assert np.array_equal(st[0].nu["model/~/linear"]["b"].numpy(), nu["model/~/linear"]["b"])
+    with open(tmp_path / "bad.pickle", "wb") as f:
+        pickle.dump({"model/~/linear": {"w": np.zeros((2, 2), np.float64)}}, f, protocol=4)
+    with pytest.raises(ValueError):
+        pt.read_haiku_params(str(tmp_path / "bad.pickle"))
+
+
+def test_reference_init_fixture():
+    """tests/golden/ref_init_params.npz = the arrays inside the reference's Test/lunar_lander/{params,opt_state}.pickle
+    (tests/golden/extract_ref_init.py). What the reference's own fixture pins about this path: the haiku tree of
+    LunarLander/dddqn.py:19-22 at D = 9 (8 obs + the ObsWrapper column, env.py:19-24) -- leaf names, [in, out] weight
+    layout, hk.Linear's default init (TruncatedNormal(1/sqrt(fan_in)) cut at 2 sigma, zero biases) that oracle_np.init_params
+    restates -- and optax.adamw's initial state (count 0, zero moments). Where the reference is present (build container)
+    the committed arrays are re-read from its files."""
+    z = np.load(os.path.join(GOLD, "ref_init_params.npz"), allow_pickle=False)
+    want = {("", "w"): (9, 32), ("", "b"): (32,), ("_1", "w"): (32, 64), ("_1", "b"): (64,), ("_2", "w"): (64, 1), ("_2", "b"): (1,),
+            ("_3", "w"): (64, 4), ("_3", "b"): (4,)}
+    for (sfx, leaf), shp in want.items():
+        a = z[f"model/~/linear{sfx}/{leaf}"]
+        assert a.shape == shp and a.dtype == np.float32
+        if leaf == "b":
+            assert not a.any()
+        else:
+            fan_in = shp[0]
+            assert np.abs(a).max() <= 2.0 / np.sqrt(fan_in) + 1e-6 and 0.6 / np.sqrt(fan_in) < a.std() < 1.0 / np.sqrt(fan_in)
+        assert not z[f"opt/mu/model/~/linear{sfx}/{leaf}"].any() and not z[f"opt/nu/model/~/linear{sfx}/{leaf}"].any()
+    assert int(z["opt/count"][0]) == 0
+    # the restatement's initialiser draws from the same family (same bounds; std of a 2-sigma truncated normal = 0.88 sigma)
+    P = onp.init_params((9, 32, 64, 4), 0)
+    w1 = P[:9 * 32]
+    assert np.abs(w1).max() <= 2.0 / 3.0 + 1e-6 and not P[9 * 32:9 * 32 + 32].any()
+    ref_dir = "/root/reference/Test/lunar_lander"
+    if os.path.isdir(ref_dir):
+        from deep_q_learning_amd.General.Base import pickle_tokens as pt
+        tree = pt.read_haiku_params(os.path.join(ref_dir, "params.pickle"))
+        assert list(tree) == ["model/~/linear", "model/~/linear_1", "model/~/linear_2", "model/~/linear_3"]
+        for m, leaves in tree.items():
+            for k, v in leaves.items():
+                assert np.array_equal(v, z[f"{m}/{k}"])
+        count, mu, nu, n_empty = pt.read_adam_state(os.path.join(ref_dir, "opt_state.pickle"))
+        assert count == 0 and n_empty == 2                      # optax.adamw = chain(scale_by_adam, add_decayed_weights, scale)
