@@ -13,7 +13,8 @@ OPT_ADAM, OPT_ADAMW = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
 ENV_SYNTHETIC, ENV_CARTPOLE = 0, 1
-FLAG_NO_HANDOVER, FLAG_NO_ACTOR16, FLAG_BF16_F32_ACTOR, FLAG_BIG_ROWS = 1, 2, 4, 8
+FLAG_NO_HANDOVER, FLAG_NO_ACTOR16, FLAG_BF16_F32_ACTOR, FLAG_BIG_ROWS, FLAG_PW_SEGMENTS, FLAG_PW_CHUNKS = 1, 2, 4, 8, 16, 32
+CNN_FLAG_FC_WIDE_TILE, CNN_FLAG_NO_SIDE_STREAM = 1, 2
 ABI_VERSION = 2
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
  BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,
@@ -80,8 +81,11 @@ SIGNATURES = {
     "dqn_allreduce_grads": [_P, _P],
     "dqn_comm_count_host": [_P, C.POINTER(_I32)],
     "dqn_device_errors_host": [_P, C.POINTER(_I64)],
+    "dqn_clear_device_errors": [_P],
+    "dqn_debug_withhold_handover": [_P, _I32],
     "dqn_cnn_create": [_I32, _I32, _I32, C.POINTER(_P)],
     "dqn_cnn_destroy": [_P],
+    "dqn_cnn_set_flags": [_P, _I32],
     "dqn_cnn_param_count": [_P, C.POINTER(_I64)],
     "dqn_cnn_set_params": [_P, C.c_int, _P, C.c_int, _P],
     "dqn_cnn_forward": [_P, C.c_int, _P, _I32, _P, _P],

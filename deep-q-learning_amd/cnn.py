@@ -29,6 +29,10 @@ class CnnEngine:
         L.check(self.lib.dqn_cnn_param_count(self.h, C.byref(n)))
         self.param_count = n.value
 
+    def set_flags(self, flags: int):
+        """diagnostics (tests): _lib.CNN_FLAG_FC_WIDE_TILE | CNN_FLAG_NO_SIDE_STREAM; results stay bit-identical"""
+        L.check(self.lib.dqn_cnn_set_flags(self.h, int(flags)))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.dqn_cnn_destroy(self.h)

@@ -85,6 +85,7 @@ struct dqn_handle {
     float *loss_part = nullptr, *loss_dev = nullptr, *scratch = nullptr;
     int *tile_cnt = nullptr;                                      // per-tile hand-over counters of the fused forward + row backward
     float *big_slab = nullptr, *big_colsum = nullptr;             // large-batch path (dqn_net_big.hip): split-K partial tiles, per-row-tile column sums
+    float *pw_part = nullptr; int pw_force = 0;                   // per-segment priority maxima of k_per_write_seg; DQN_FLAG_PW_* (tests)
     unsigned int *wmax_tmp = nullptr;                             // batch max of the raw IS weights (API sampler -> normalise)
     int num_cus = 256;                                            // hipDeviceAttributeMultiprocessorCount of the handle's device
     float *env_obs = nullptr, *env_next = nullptr, *env_r = nullptr; int32_t *env_a = nullptr; uint8_t *env_d = nullptr;
@@ -93,6 +94,7 @@ struct dqn_handle {
     bool no_handover = false;                                     // DQN_FLAG_NO_HANDOVER: no in-launch waits (no sampler workgroups, k_bwd_rows on its own)
     bool no_actor16 = false, f32_actor = false;                   // DQN_FLAG_NO_ACTOR16 / DQN_FLAG_BF16_F32_ACTOR
     bool big_any = false;                                         // DQN_FLAG_BIG_ROWS
+    int withhold = 0;                                             // dqn_debug_withhold_handover
     int tile_stride = 0;                                          // tile_cnt: [tile_stride] arrival counters + [tile_stride] consumed counts
     float p_done = 0.01f;
     int env_kind = 0, env_max_steps = 500; int32_t *env_t = nullptr; float env_term_reward = 1.0f;
@@ -126,8 +128,8 @@ static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, 
         for (int i = 0; i < n; ++i) plain = plain && !p[i].act_out && !p[i].px && p[i].x;
         if (plain) { launch_big_forward(s, h->m, p, n, B, h->num_cus); return; }
     }
-    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
-    else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride);
+    if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride, h->withhold);
+    else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride, h->withhold);
 }
 static void L_bwd(dqn_handle *h, hipStream_t s, const BwdArgs &g, int B) {
     if (h->bf16) launch_bwd_rows_bf16(s, h->m, g, B, h->st); else launch_bwd_rows(s, h->m, g, B, h->st);
@@ -167,7 +169,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     REQUIRE(cfg->optimizer == DQN_OPT_ADAM || cfg->optimizer == DQN_OPT_ADAMW, "unknown optimizer");
     REQUIRE(cfg->world_size >= 1, "world_size must be >= 1");
     REQUIRE(cfg->n_step >= 0 && cfg->n_step <= 8, "n_step %d out of range [0,8]", cfg->n_step);
-    REQUIRE((cfg->flags & ~15) == 0, "unknown flags 0x%x", cfg->flags);
+    REQUIRE((cfg->flags & ~63) == 0, "unknown flags 0x%x", cfg->flags);
     REQUIRE(cfg->n_step <= 1 || cfg->capacity >= 64ll * cfg->max_batch, "n_step > 1 needs capacity >= 64 * max_batch "
             "(the n-step actor runs in k_actor only, whose steps of one launch must fit the ring)");
 
@@ -186,6 +188,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->no_actor16 = (cfg->flags & DQN_FLAG_NO_ACTOR16) != 0;
     h->f32_actor = (cfg->flags & DQN_FLAG_BF16_F32_ACTOR) != 0;
     h->big_any = (cfg->flags & DQN_FLAG_BIG_ROWS) != 0;
+    h->pw_force = (cfg->flags & DQN_FLAG_PW_SEGMENTS) ? 2 : ((cfg->flags & DQN_FLAG_PW_CHUNKS) ? 1 : 0);
     h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
     h->gamma_n = cfg->gamma;
     for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
@@ -213,7 +216,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->states, N * D * 4, DQN_BUF_STATES); add(&h->observations, N * D * 4, DQN_BUF_OBSERVATIONS);
     add(&h->rewards, N * 4, DQN_BUF_REWARDS); add(&h->actions, N * 4, DQN_BUF_ACTIONS);
     add(&h->dones, N, DQN_BUF_DONES);
-    if (cfg->use_per) { add(&h->tree, 2 * h->Ntree * 4, DQN_BUF_TREE); add(&h->stamp, h->Ntree * 8); }
+    if (cfg->use_per) { add(&h->tree, 2 * h->Ntree * 4, DQN_BUF_TREE); add(&h->stamp, h->Ntree * 8); add(&h->pw_part, 8192 * 4); }
     add(&h->bs, Bp * D * 4); add(&h->bs2, Bp * D * 4); add(&h->br, Bp * 4); add(&h->bw_raw, Bp * 4);
     add(&h->bisw, Bp * 4, DQN_BUF_BATCH_ISW); add(&h->btd, Bp * 4, DQN_BUF_BATCH_TD); add(&h->btd_abs, Bp * 4);
     add(&h->bdf, Bp * 4); add(&h->ba, Bp * 4); add(&h->bidx, Bp * 4, DQN_BUF_BATCH_IDX); add(&h->bd, Bp);
@@ -431,7 +434,7 @@ static int per_write_sorted(dqn_handle *h, const int32_t *idx, const float *val,
     if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
     REQUIRE(B >= 1, "B must be >= 1");
     launch_per_write_sorted((hipStream_t)stream, h->st, h->tree, h->Ntree, h->L, idx, val, B, mode,
-                            h->cfg.per_alpha, h->cfg.per_eps);
+                            h->cfg.per_alpha, h->cfg.per_eps, h->pw_part, h->pw_force);
     HIP_TRY(hipGetLastError());
     return DQN_OK;
 }
@@ -557,7 +560,7 @@ static void enqueue_per_writeback(dqn_handle *h, int B, hipStream_t st) {
     // the batch indices come from dqn_per_sample's stratified descent: non-decreasing
     arm(h);
     launch_per_write_sorted(st, h->st, h->tree, h->Ntree, h->L, h->bidx, h->btd_abs, B, 1,
-                            h->cfg.per_alpha, h->cfg.per_eps);
+                            h->cfg.per_alpha, h->cfg.per_eps, h->pw_part, h->pw_force);
     mark(h, st, "per_update");
 }
 
@@ -999,6 +1002,31 @@ extern "C" int dqn_comm_count_host(dqn_handle *h, int32_t *ranks) {
     const int e = g_rccl.CommCount(h->comm, &n);
     if (e) return fail(DQN_ERR_COMM, "ncclCommCount: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
     *ranks = n;
+    return DQN_OK;
+}
+
+/* Diagnostic (tests): with on != 0 the partner passes of the fused forward launch no longer count themselves in, so every
+ * pass-0 workgroup sits out its bounded wait (DQN_WAIT_TICKS, 0.2 s), gives up, bumps the error count and poisons the loss --
+ * the path a partitioned / shared device would take. Captured launches are dropped (the switch is a kernel argument). */
+extern "C" int dqn_debug_withhold_handover(dqn_handle *h, int32_t on) {
+    REQUIRE(h, "null handle");
+    HIP_TRY(hipDeviceSynchronize());
+    destroy_graphs(h);
+    h->withhold = on ? 1 : 0;
+    return DQN_OK;
+}
+
+/* After dqn_device_errors_host has reported give-ups: bring the hand-over words back to their initial state (per-tile
+ * arrival / consumed counters, arrival ticket, fill count, error count) so that the handle can be used again. The results of
+ * the launches that timed out stay what they are (NaN losses; parameters updated from incomplete rows): reload them. */
+extern "C" int dqn_clear_device_errors(dqn_handle *h) {
+    REQUIRE(h, "null handle");
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->tile_cnt) HIP_TRY(hipMemset(h->tile_cnt, 0, (size_t)h->tile_stride * 2 * 4));
+    const unsigned int z = 0;
+    HIP_TRY(hipMemcpy(&h->st->err_count, &z, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&h->st->arrive, &z, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&h->st->fill_cnt, &z, 4, hipMemcpyHostToDevice));
     return DQN_OK;
 }
 

@@ -941,6 +941,7 @@ struct dqn_cnn_handle {
     float *ring_r = nullptr, *ring_d = nullptr, *stage_r = nullptr, *stage_d = nullptr;
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
+    int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
 };
 
 struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
@@ -1040,6 +1041,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
 extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (!h) return DQN_OK;
     (void)hipDeviceSynchronize();
+    if (h->side_kept) h->side = h->side_kept;
     if (h->side) (void)hipStreamDestroy(h->side);
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -1113,12 +1115,25 @@ extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
     return DQN_OK;
 }
 
+/* diagnostics (tests): DQN_CNN_FLAG_FC_WIDE_TILE takes the 128 x 128 fc tile of the bf16 mode (normally from 8 192 rows) at every
+ * batch size; DQN_CNN_FLAG_NO_SIDE_STREAM runs the target pass, the dW kernels and the fc leaf's optimizer step in stream order
+ * on the caller's stream instead of the handle's side stream. Both leave every result bit-identical. */
+extern "C" int dqn_cnn_set_flags(dqn_cnn_handle *h, int32_t flags) {
+    CNN_REQ(h, "null handle");
+    CNN_REQ((flags & ~(DQN_CNN_FLAG_FC_WIDE_TILE | DQN_CNN_FLAG_NO_SIDE_STREAM)) == 0, "unknown dqn_cnn flag");
+    (void)hipDeviceSynchronize();
+    if (h->side && !h->side_kept) h->side_kept = h->side;
+    h->side = (flags & DQN_CNN_FLAG_NO_SIDE_STREAM) ? nullptr : h->side_kept;
+    h->flags = flags;
+    return DQN_OK;
+}
+
 template <typename TI, typename TC, int L>
-static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int images1, const TC *wt, const float *bias, TC *out) {
+static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int images1, const TC *wt, const float *bias, TC *out, bool wide = false) {
     typedef CnnGeo<L> G;
     const int M = B * G::OH * G::OW;
     if constexpr (sizeof(TC) == 2 && L == 3) {
-        if (B >= 8192) {
+        if (B >= 8192 || wide) {
             typedef CnnTile<L, 1> T;
             const int BM = T::MT * T::WM * T::TM, BN = T::MT * T::WN * T::TN;
             DQN_LAUNCH((k_cnn_layer<TI, TC, L, 1>), dim3((unsigned)((M + BM - 1) / BM * (G::OC / BN))), dim3(256), 0, s, M, in, in2, images1, wt, bias, out);
@@ -1141,7 +1156,7 @@ static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, i
     launch_layer<uint8_t, TC, 0>(s, B, frames, frames2 ? frames2 : frames, B1, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
     launch_layer<TC, TC, 1>(s, B, a0, a0, B, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
     launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
-    launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3);
+    launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3, (h->flags & DQN_CNN_FLAG_FC_WIDE_TILE) != 0);
     hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
 static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr) {

@@ -71,7 +71,7 @@ struct BwdArgs {
     float *loss_part;                  // [ceil(B/16)]
 };
 
-struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; int tiles; };   // tile_cnt: [tiles] arrival counters + [tiles] consumed counts   // row backward fused into the forward launch (k_qnet_fwd<.., FUSE>)
+struct FuseBwd { BwdArgs g; int *tile_cnt; DqnState *st; int tiles; int withhold; };   // withhold (diagnostic, dqn_debug_withhold_handover): the partner passes do not count themselves in   // tile_cnt: [tiles] arrival counters + [tiles] consumed counts   // row backward fused into the forward launch (k_qnet_fwd<.., FUSE>)
 
 struct PwArgs {             // sorted PER write-back run by surplus workgroups of k_dw when tree != NULL
     float *tree; long long N; int L; const int32_t *idx; const float *td_abs; int B; float alpha, eps;
@@ -86,7 +86,7 @@ void launch_pack_w2k16(hipStream_t s, const NetDims &m, const float *params, flo
 // fuse != NULL (f32, three passes, 3 * ceil(B/16) <= 256, batch weights final before the launch): the pass-0 workgroups
 // also run the row backward of their tiles (k_bwd_rows' work); tile_cnt = ceil(B/16) zeroed counters
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
-                     const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0);
+                     const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0, int withhold = 0);
 // T vector env steps of n envs in one launch (+ leaf insert, + presampling of the next PER batch); dqn_actor.hip.
 // num_cus: the device's CU count -- tree, sampler and actor workgroups wait for each other inside the launch, so the grid
 // is sized to be resident as a whole; no_wide: never the 16-env small-net kernel (diagnostic). Returns whether the PER
@@ -143,8 +143,10 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        unsigned int *wmax_bits, int num_cus, bool nt_out);
 void launch_env_time_feature(hipStream_t st_, const DqnState *st, float *observations, uint8_t *dones, float *env_obs,
                              int32_t *env_t, long long cap, int D, int n, int max_steps);
+// pw_part: 8 192 floats of scratch for the segment kernel (k_per_write_seg, large batches); force: 0 = by batch size,
+// 1 = always the wave-per-chunk kernel, 2 = always the segment kernel (tests)
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
-                             const float *val, int B, int mode, float alpha, float eps);
+                             const float *val, int B, int mode, float alpha, float eps, float *pw_part = nullptr, int force = 0);
 void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap);
 void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st, const unsigned int *wmax_bits);
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
@@ -155,7 +157,7 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 long long bf16_pack_elems(const NetDims &m);
 void launch_pack_bf16(hipStream_t s, const NetDims &m, const float *params, float *pack);
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp = nullptr,
-                          const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0);
+                          const BwdArgs *fuse = nullptr, int *tile_cnt = nullptr, DqnState *st = nullptr, int tile_stride = 0, int withhold = 0);
 void launch_bwd_rows_bf16(hipStream_t s, const NetDims &m, const BwdArgs &g, int B, DqnState *st);
 void launch_dw_bf16(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2,
                     const float *pdz1, const float *pdz2, const float *pdz3, int B, float *grad,

@@ -494,7 +494,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
             // passes 1, 2: the Q rows above were L1-bypassing stores of wave 0; drain them, then count this pass in
             if (wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, 1u);
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, fb.withhold ? 0u : 1u);
             }
             return;
         }
@@ -509,6 +509,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         float wi = 1.0f, wmax = 1.0f;
         if (rowt && g.w_raw) { wi = g.w_raw[irow]; wmax = fb.st->wmax; }
         for (int t = tid; t < 16 * s3; t += 256) l3[t] = 0.0f;
+        bool gave_up = false;                                        // (thread 0)
         if (tid == 0) {
             // bounded wait (dqn_device.h): the launcher only fuses grids that are resident as a whole, so the partners are
             // running; should that ever not hold, the kernel still ends, the loss turns NaN and the error count goes up
@@ -516,7 +517,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
             // what it has already consumed in seen[]: a late partner of a timed-out launch can never satisfy a later wait.
             unsigned *cnt = reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, *seen = reinterpret_cast<unsigned *>(fb.tile_cnt) + fb.tiles + tile;
             const unsigned want = *seen + 2u;
-            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); if (true) g.loss_part[tile] = __int_as_float(0x7fc00000); }
+            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); gave_up = true; }
             *seen = want;
         }
         LDS_BARRIER();                                               // partners' rows are in L2; l3 is zeroed
@@ -585,7 +586,8 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
         if (tid == 0) {
             float sl = 0.0f;
             for (int k = 0; k < 16; ++k) sl = sl + lrow[k];
-            g.loss_part[tile] = sl + (g.loss_part[tile] != g.loss_part[tile] ? g.loss_part[tile] : 0.0f);   // keeps a wait-timeout NaN
+            g.loss_part[tile] = gave_up ? __int_as_float(0x7fc00000) : sl;   // a wait that gave up poisons THIS launch's loss (r02 kept
+                                                                             // the NaN by re-reading the slot: sticky across launches)
         }
         {   // stash dz3 (packed, K = batch, C = 16)
             const int rl = tid >> 4, c = tid & 15;
@@ -630,7 +632,7 @@ k_qnet_fwd(NetDims m, FwdPasses passes, int B, SampleArgs smp, FuseBwd fb) {
 static inline int tn_of(int H) { const int ct = H / 16; return ct <= 4 ? 1 : (ct <= 8 ? 2 : 4); }
 
 void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
-                     const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride) {
+                     const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride, int withhold) {
     FwdPasses ps{};
     for (int i = 0; i < npass; ++i) ps.p[i] = passes[i];
     const SampleArgs sa = smp ? *smp : SampleArgs{};
@@ -638,7 +640,7 @@ void launch_qnet_fwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int
     size_t lds = sizeof(float) * (16 * (m.KQ1 * 16 + 4) + 16 * (m.H1 + 4) + 16 * (m.H2 + 4) + 256 + 32 + 528);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
-        FuseBwd fb{*fuse, tile_cnt, st, tile_stride};
+        FuseBwd fb{*fuse, tile_cnt, st, tile_stride, withhold};
         lds += sizeof(float) * (16 * (m.H2 + 4) + 16);
 #define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd<A1, A2, true>), grid, block, lds, s, m, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)

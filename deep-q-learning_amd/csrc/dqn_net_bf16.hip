@@ -340,7 +340,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         if (blockIdx.y != 0) {
             if (wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the Q rows above have left this CU
-                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, 1u);
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, fb.withhold ? 0u : 1u);
             }
             return;
         }
@@ -358,6 +358,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         if (rowt && g.w_raw) { wi = g.w_raw[irow]; wmax = fb.st->wmax; }
         for (int t = tid; t < 16 * s3; t += 256) l3[t] = (__bf16)0.0f;
         for (int t = tid; t < 16 * (KH - m.H2); t += 256) lz2[(t / (KH - m.H2)) * s2 + m.H2 + t % (KH - m.H2)] = (__bf16)0.0f;
+        bool gave_up = false;                                        // (thread 0)
         if (tid == 0) {
             // bounded wait (dqn_device.h): the launcher only fuses grids that are resident as a whole, so the partners are
             // running; should that ever not hold, the kernel still ends, the loss turns NaN and the error count goes up
@@ -365,7 +366,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
             // what it has already consumed in seen[]: a late partner of a timed-out launch can never satisfy a later wait.
             unsigned *cnt = reinterpret_cast<unsigned *>(fb.tile_cnt) + tile, *seen = reinterpret_cast<unsigned *>(fb.tile_cnt) + fb.tiles + tile;
             const unsigned want = *seen + 2u;
-            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); if (true && tile < (B + 15) / 16) g.loss_part[tile] = __int_as_float(0x7fc00000); }
+            if (!wait_word_eq(cnt, want, 2)) { flag_wait_timeout(fb.st); gave_up = true; }
             *seen = want;
         }
         LDS_BARRIER();
@@ -425,7 +426,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
         if (tid == 0 && tile < (B + 15) / 16) {
             float sl = 0.0f;
             for (int k = 0; k < 16; ++k) sl = sl + lrow[k];
-            g.loss_part[tile] = sl + (g.loss_part[tile] != g.loss_part[tile] ? g.loss_part[tile] : 0.0f);
+            g.loss_part[tile] = gave_up ? __int_as_float(0x7fc00000) : sl;
         }
         pdz3[pidx16(KQb, row0 + (tid >> 4), tid & 15)] = l3[(tid >> 4) * s3 + (tid & 15)];
         {   // dz2 = (dz3 . WH^T) * (h2 > 0)
@@ -470,7 +471,7 @@ k_qnet_fwd16(NetDims m, Dims16 d, FwdPasses16 passes, int B, SampleArgs smp, Fus
 static inline int tiles16(int B) { return 2 * ((B + 31) / 32); }
 
 void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const SampleArgs *smp,
-                          const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride) {
+                          const BwdArgs *fuse, int *tile_cnt, DqnState *st, int tile_stride, int withhold) {
     FwdPasses16 ps{};
     bool stash = false;
     for (int i = 0; i < npass; ++i) { ps.p[i] = passes[i]; stash |= passes[i].px != nullptr; }
@@ -480,7 +481,7 @@ void launch_qnet_fwd_bf16(hipStream_t s, const NetDims &m, const FwdPass *passes
     size_t lds = 2 * (16 * (d.KQ1 * 32 + 8) + 16 * (d.KQ2 * 32 + 8) + 16 * (d.KQH * 32 + 8)) + 4 * (256 + 32 + 528);
     const int t1 = tn_of(m.H1), t2 = tn_of(m.H2);
     if (fuse) {
-        const FuseBwd fb{*fuse, tile_cnt, st, tile_stride};
+        const FuseBwd fb{*fuse, tile_cnt, st, tile_stride, withhold};
         lds += 2 * 16 * (d.KQH * 32 + 8) + 4 * 16;
 #define FWD_CASE(A1, A2) if (t1 == A1 && t2 == A2) { DQN_LAUNCH((k_qnet_fwd16<A1, A2, true>), grid, block, lds, s, m, d, ps, B, sa, fb); return; }
         FWD_CASE(1, 1) FWD_CASE(1, 2) FWD_CASE(1, 4) FWD_CASE(2, 1) FWD_CASE(2, 2) FWD_CASE(2, 4)

@@ -641,6 +641,149 @@ k_per_top(DqnState *st, float *tree, int L) {
     if (tid == 0) st->epoch += 1ull;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// r03: the sorted write-back rebuilt for BANDWIDTH (large batches; the wave-per-64-positions kernel above stays for small
+// ones and inside k_dw). Instead of walking up from every touched leaf (per item: L scattered sibling reads + L scattered
+// parent writes), the LEAF SPACE is cut into segments of 2^PWS_LOG leaves, one workgroup each:
+//   * the workgroup finds its slice [lo, hi) of the sorted batch by two interleaved 64-ary searches (4 dependent probes at
+//     B = 2^20 instead of 20), leaves at once if the slice is empty (nothing of that subtree is read or written);
+//   * otherwise it loads the segment's leaves (coalesced 16-B loads) into an LDS heap, applies its batch items there (the last
+//     of a run of equal leaves wins -- the highest batch position, as everywhere), and recomputes EVERY inner node of the
+//     subtree as left + right: three levels in registers (a thread owns 8 consecutive leaves), six by wave shuffles, the
+//     rest through LDS. Untouched nodes are re-derived from untouched children: the tree's invariant (a parent is always
+//     fl(left + right), never delta-added) makes that the value they already have -- the result is bit-identical to the
+//     touched-path update of the restatement;
+//   * leaves and inner nodes go back as dense, coalesced stores (one contiguous run per level).
+// k_per_top_seg then rebuilds the levels above the segment roots from the N / 2^PWS_LOG roots (one workgroup, LDS) and folds
+// the per-segment priority maxima into the running max. No atomics anywhere: hundreds of workgroups bumping one word
+// serialise at ~0.1 us each.
+// Traffic at L = 20 with every segment touched: 4 MB leaves in, 4 + 4 MB out, 8 B per item -- independent of the tree depth.
+#define PWS_LOG 11
+#define PWS_MIN_B 8192              // below: the wave-per-64-positions kernel (touched paths only) + k_per_top
+#define PWS_MAX_ROOT_LOG 13          // at most 2^13 segment roots in the top kernel's LDS heap (L <= 24)
+
+__global__ void __launch_bounds__(256)
+k_per_write_seg(float *__restrict__ tree, int L, const int32_t *__restrict__ idx, const float *__restrict__ val, int B,
+                int mode, float alpha, float eps, float *__restrict__ pmax_part) {
+    __shared__ __attribute__((aligned(16))) float heap[2 << PWS_LOG];      // heap[1] = segment root, leaf i at heap[S + i]
+    __shared__ int bounds[2];
+    __shared__ float wmaxs[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SL = L < PWS_LOG ? L : PWS_LOG, S = 1 << SL;
+    const int seg = blockIdx.x;
+    const long long N = 1ll << L;
+    if (wave == 0) {
+        // first batch position whose leaf is >= key, for key = seg * S (lo) and (seg + 1) * S (hi): 64-ary searches over the
+        // non-decreasing idx[], both in flight together
+        const int key0 = seg << SL, key1 = (seg + 1) << SL;
+        int a0 = 0, b0 = B, a1 = 0, b1 = B;
+        while (b0 > a0 || b1 > a1) {
+            const int st0 = (b0 - a0 + 63) >> 6, st1 = (b1 - a1 + 63) >> 6;
+            const int p0 = a0 + lane * st0, p1 = a1 + lane * st1;
+            const bool in0 = b0 > a0 && p0 < b0, in1 = b1 > a1 && p1 < b1;
+            const int v0 = in0 ? idx[p0] : 0x7fffffff, v1 = in1 ? idx[p1] : 0x7fffffff;
+            const int c0 = __popcll(__ballot(in0 && v0 < key0)), c1 = __popcll(__ballot(in1 && v1 < key1));
+            if (b0 > a0) { if (c0 == 0) b0 = a0; else { const int na = a0 + (c0 - 1) * st0 + 1, nb = a0 + c0 * st0; a0 = na; b0 = nb < b0 ? nb : b0; } }
+            if (b1 > a1) { if (c1 == 0) b1 = a1; else { const int na = a1 + (c1 - 1) * st1 + 1, nb = a1 + c1 * st1; a1 = na; b1 = nb < b1 ? nb : b1; } }
+        }
+        if (lane == 0) { bounds[0] = a0; bounds[1] = a1; }
+    }
+    __syncthreads();
+    const int lo = bounds[0], hi = bounds[1];
+    if (lo >= hi) { if (tid == 0) pmax_part[seg] = 0.0f; return; }
+    float *leaves = tree + N + ((long long)seg << SL);
+    const int per = S >= 2048 ? 8 : (S >= 256 ? S / 256 : 1);               // leaves per thread (S < 256: threads >= S idle)
+    const bool act = tid * per < S;
+    float lf[8];
+    if (per == 8) {
+        const float4 x0 = reinterpret_cast<const float4 *>(leaves)[2 * tid], x1 = reinterpret_cast<const float4 *>(leaves)[2 * tid + 1];
+        lf[0] = x0.x; lf[1] = x0.y; lf[2] = x0.z; lf[3] = x0.w; lf[4] = x1.x; lf[5] = x1.y; lf[6] = x1.z; lf[7] = x1.w;
+        reinterpret_cast<float4 *>(heap + S)[2 * tid] = x0; reinterpret_cast<float4 *>(heap + S)[2 * tid + 1] = x1;
+    } else if (act) {
+        for (int k = 0; k < per; ++k) { lf[k] = leaves[tid * per + k]; heap[S + tid * per + k] = lf[k]; }
+    }
+    __syncthreads();
+    float lmax = 0.0f;
+    for (int j = lo + tid; j < hi; j += 256) {
+        const int leaf = idx[j];
+        const float p = (mode == 0) ? val[j] : pow_det(val[j] + eps, alpha);
+        lmax = fmaxf(lmax, p);
+        const bool loser = j + 1 < B && idx[j + 1] == leaf;                 // a later batch position holds the same leaf
+        if (!loser) heap[S + (leaf - (seg << SL))] = p;
+    }
+    __syncthreads();
+    // ---- all inner nodes, bottom-up, each as left + right
+    if (per == 8) {
+        const float4 x0 = reinterpret_cast<const float4 *>(heap + S)[2 * tid], x1 = reinterpret_cast<const float4 *>(heap + S)[2 * tid + 1];
+        reinterpret_cast<float4 *>(leaves)[2 * tid] = x0; reinterpret_cast<float4 *>(leaves)[2 * tid + 1] = x1;
+        const float s0 = x0.x + x0.y, s1 = x0.z + x0.w, s2 = x1.x + x1.y, s3 = x1.z + x1.w;     // depth SL-1: nodes S/2 + 4 tid ..
+        const float t0 = s0 + s1, t1 = s2 + s3;                                                  // depth SL-2: S/4 + 2 tid ..
+        float v = t0 + t1;                                                                       // depth SL-3: S/8 + tid
+        reinterpret_cast<float4 *>(heap + (S >> 1))[tid] = float4{s0, s1, s2, s3};
+        reinterpret_cast<float2 *>(heap + (S >> 2))[tid] = float2{t0, t1};
+        heap[(S >> 3) + tid] = v;
+        // six levels inside the wave: at step s the lanes that are multiples of 2^s hold the node of 2^s threads
+#pragma unroll
+        for (int s = 1; s <= 6; ++s) {
+            const float r = __shfl_down(v, 1 << (s - 1), 64);
+            v = v + r;                                                       // left (this lane) + right
+            if ((lane & ((1 << s) - 1)) == 0) heap[(S >> (3 + s)) + (tid >> s)] = v;
+        }
+        // wave w's lane 0 wrote node (S >> 9) + w = 4 + w (S = 2048): two more levels by one thread
+        __syncthreads();
+        if (tid == 0) { heap[2] = heap[4] + heap[5]; heap[3] = heap[6] + heap[7]; heap[1] = heap[2] + heap[3]; }
+        __syncthreads();
+    } else {
+        if (act) for (int k = 0; k < per; ++k) leaves[tid * per + k] = heap[S + tid * per + k];
+        for (int d = SL - 1; d >= 0; --d) {
+            const int cnt = 1 << d;
+            for (int t = tid; t < cnt; t += 256) heap[cnt + t] = heap[2 * (cnt + t)] + heap[2 * (cnt + t) + 1];
+            __syncthreads();
+        }
+    }
+    // ---- inner nodes out: heap index k at local depth d = floor(log2 k) is global node 2^(L-SL+d) + seg * 2^d + (k - 2^d)
+    for (int k = tid; k < S; k += 256) {
+        if (k == 0) continue;
+        const int d = 31 - __clz(k);
+        tree[(1ll << (L - SL + d)) + ((long long)seg << d) + (k - (1 << d))] = heap[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+    if (lane == 0) wmaxs[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) pmax_part[seg] = fmaxf(fmaxf(wmaxs[0], wmaxs[1]), fmaxf(wmaxs[2], wmaxs[3]));
+}
+
+// levels above the segment roots (depth L - SL, R = 2^(L-SL) nodes, final in HBM) + running max + epoch
+__global__ void __launch_bounds__(1024)
+k_per_top_seg(DqnState *st, float *tree, int L, const float *__restrict__ pmax_part) {
+    extern __shared__ __attribute__((aligned(16))) float top[];             // heap of 2 R floats
+    __shared__ float wm[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int SL = L < PWS_LOG ? L : PWS_LOG, RL = L - SL, R = 1 << RL;
+    float m = 0.0f;
+    for (int j = tid; j < R; j += nt) { top[R + j] = tree[R + j]; m = fmaxf(m, pmax_part[j]); }
+    __syncthreads();
+    for (int d = RL - 1; d >= 0; --d) {
+        const int cnt = 1 << d;
+        for (int j = tid; j < cnt; j += nt) {
+            const int p = cnt + j;
+            const float v = top[2 * p] + top[2 * p + 1];
+            top[p] = v;
+            tree[p] = v;
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) wm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (nt >> 6); ++w) m = fmaxf(m, wm[w]);
+        if (m > st->pmax) st->pmax = m;                                      // running max priority (max is order-independent)
+        st->epoch += 1ull;
+    }
+}
+
 // ------------------------------------------------- leaf-range insert (ring add with PER)
 // device code: per_add_range_wg / per_add_slow in dqn_per_device.h
 __global__ void __launch_bounds__(1024)
@@ -770,8 +913,17 @@ void launch_per_top(hipStream_t st_, DqnState *st, float *tree, int L) {
     DQN_LAUNCH(k_per_top, dim3(1), dim3(n / 2 < 1024 ? (n / 2 < 64 ? 64 : n / 2) : 1024), sizeof(float) * n, st_, st, tree, L);
 }
 
+// pw_part: scratch of 2^PWS_MAX_ROOT_LOG floats (per-segment priority maxima), or NULL
+bool per_write_seg_applies(int L, int B) { return B >= PWS_MIN_B && L - (L < PWS_LOG ? L : PWS_LOG) <= PWS_MAX_ROOT_LOG; }
+
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
-                             const float *val, int B, int mode, float alpha, float eps) {
+                             const float *val, int B, int mode, float alpha, float eps, float *pw_part, int force) {
+    if (pw_part && force != 1 && (force == 2 || per_write_seg_applies(L, B)) && L - (L < PWS_LOG ? L : PWS_LOG) <= PWS_MAX_ROOT_LOG) {
+        const int SL = L < PWS_LOG ? L : PWS_LOG, R = 1 << (L - SL);
+        DQN_LAUNCH(k_per_write_seg, dim3(R), dim3(256), 0, st_, tree, L, idx, val, B, mode, alpha, eps, pw_part);
+        DQN_LAUNCH(k_per_top_seg, dim3(1), dim3(R >= 1024 ? 1024 : (R < 64 ? 64 : R)), sizeof(float) * 2 * R, st_, st, tree, L, pw_part);
+        return;
+    }
     DQN_LAUNCH(k_per_write_sorted, dim3((B + 63) / 64), dim3(64), 0, st_, st, tree, N, L, idx, val, B, mode,
                        alpha, eps);
     launch_per_top(st_, st, tree, L);

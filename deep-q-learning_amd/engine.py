@@ -390,6 +390,14 @@ class Engine:
         L.check(self.lib.dqn_device_errors_host(self.h, C.byref(n)))
         return n.value
 
+    def clear_device_errors(self):
+        """after device_errors() != 0: hand-over words and the error count back to their initial state (synchronises)"""
+        L.check(self.lib.dqn_clear_device_errors(self.h))
+
+    def debug_withhold_handover(self, on: bool):
+        """diagnostic (tests): make the fused update's hand-over waits run into their 0.2 s bound"""
+        L.check(self.lib.dqn_debug_withhold_handover(self.h, int(bool(on))))
+
     def allreduce_grads_native(self, stream=None):
         L.check(self.lib.dqn_allreduce_grads(self.h, self._s(stream)))
 

@@ -56,8 +56,11 @@ typedef enum {
                                     * co-resident grids; the flag forces it (tests). Same results, bit for bit. */
     DQN_FLAG_NO_ACTOR16 = 2,       /* never the 16-env small-net actor kernel */
     DQN_FLAG_BF16_F32_ACTOR = 4,   /* bf16 mode with the exact-f32 actor chain */
-    DQN_FLAG_BIG_ROWS = 8          /* take the 64-row large-batch kernels (dqn_net_big.hip; 2x256 nets, f32) for every batch of
+    DQN_FLAG_BIG_ROWS = 8,         /* take the 64-row large-batch kernels (dqn_net_big.hip; 2x256 nets) for every batch of
                                     * >= 64 rows instead of from 16 384 rows up (tests: same results at small sizes) */
+    DQN_FLAG_PW_SEGMENTS = 16,     /* sorted priority write-back: always the leaf-segment kernel (k_per_write_seg, normally from
+                                    * 8 192 batch positions) ... */
+    DQN_FLAG_PW_CHUNKS = 32        /* ... / always the wave-per-64-positions kernel. Same tree, bit for bit. */
 } dqn_flags;
 
 typedef struct dqn_handle dqn_handle;
@@ -238,6 +241,11 @@ int dqn_comm_count_host(dqn_handle *h, int32_t *ranks);   /* ncclCommCount of th
  * NaN and counts here instead of hanging the GPU. Returns the count since dqn_create (synchronises); non-zero means the
  * results since then are not to be trusted. */
 int dqn_device_errors_host(dqn_handle *h, int64_t *count);
+/* resets the hand-over words and the error count after give-ups were reported (the timed-out launches' results stay) */
+int dqn_clear_device_errors(dqn_handle *h);
+/* diagnostic (tests): the fused forward's partner passes stop counting themselves in -> every hand-over wait of the next
+ * updates runs into its bound (0.2 s), the error count goes up, the loss is NaN; on = 0 restores the normal path */
+int dqn_debug_withhold_handover(dqn_handle *h, int32_t on);
 
 /* ---- Nature-CNN dueling Q-network (BASELINE configs[4], PongNoFrameskip-v4 shape). Not in
  * the reference: the trunk (conv 32x8x8/4, 64x4x4/2, 64x3x3/1, fc 512, ReLU) ends in the reference's dueling head
@@ -249,6 +257,10 @@ int dqn_device_errors_host(dqn_handle *h, int64_t *count);
 typedef struct dqn_cnn_handle dqn_cnn_handle;
 int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out);
 int dqn_cnn_destroy(dqn_cnn_handle *h);
+/* diagnostics for the tests (results stay bit-identical): FC_WIDE_TILE = the bf16 mode's 128 x 128 fc tile (normally taken from
+ * 8 192 rows) at every batch size; NO_SIDE_STREAM = everything in stream order on the caller's stream */
+enum dqn_cnn_flags { DQN_CNN_FLAG_FC_WIDE_TILE = 1, DQN_CNN_FLAG_NO_SIDE_STREAM = 2 };
+int dqn_cnn_set_flags(dqn_cnn_handle *h, int32_t flags);
 int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n);
 int dqn_cnn_set_params(dqn_cnn_handle *h, int which_net, const float *src, int src_is_host, void *stream);
 int dqn_cnn_forward(dqn_cnn_handle *h, int which_net, const uint8_t *frames, int32_t B, float *q, void *stream);

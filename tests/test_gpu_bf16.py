@@ -221,3 +221,49 @@ def test_bf16_actor_counters_advance_without_per(dq, n_step, per):
     assert np.isfinite(first).all() and np.abs(first).max() > 0
     assert e.device_errors() == 0
     e.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_bounded_wait_gives_up_and_the_handle_recovers(dq, precision):
+    """the give-up path of the bounded in-kernel waits (csrc/dqn_device.h: wait_word_eq, 0.2 s of the
+    100 MHz clock) driven on purpose. dqn_debug_withhold_handover makes the fused forward's partner passes not count
+    themselves in: the update must RETURN (no hang), every tile's pass-0 workgroup gives up once (error count = tiles), the
+    loss is NaN. After dqn_clear_device_errors + a parameter reload the same handle runs the normal path again: no errors,
+    finite losses."""
+    import time
+    import torch
+    dims = CFGS["cfg2"]
+    B, N = 1024, 1 << 12
+    rng = np.random.default_rng(21)
+    rows = (rng.standard_normal((2048, 8)), rng.integers(0, 4, 2048), rng.standard_normal(2048), rng.standard_normal((2048, 8)), rng.random(2048) < 0.05)
+    P0 = rand_params(dims, 22)
+
+    def fresh():
+        # uniform replay: the row backward rides in the forward launch (with PER only behind the actor launch's presampling)
+        e = dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=N, use_per=False,
+                                      max_batch=B, seed=9, precision=precision))
+        e.set_params(P0); e.sync_target(); e.replay_add(*rows)
+        return e
+    e = fresh()
+    with torch.cuda.stream(e.stream):
+        e.update(B); e.stream.synchronize()                       # the normal path first (also: graphs exist and must be dropped)
+        assert e.device_errors() == 0 and np.isfinite(float(e.last_loss().item()))
+        e.debug_withhold_handover(True)
+        t0 = time.time()
+        e.update(B); e.stream.synchronize()
+        dt = time.time() - t0
+    assert 0.15 < dt < 5.0, dt                                    # sat out the 0.2 s bound once (tiles wait side by side), did not hang
+    assert e.device_errors() == (B + 15) // 16
+    assert np.isnan(float(e.last_loss().item()))
+    e.debug_withhold_handover(False)
+    e.clear_device_errors()
+    assert e.device_errors() == 0
+    # the next normal launches on the same handle are clean (its parameters carry the timed-out update: only health is
+    # compared) -- hand-over counters in step again, graphs re-captured
+    e.set_params(P0); e.sync_target()
+    with torch.cuda.stream(e.stream):
+        for _ in range(3):
+            e.update(B)
+        e.stream.synchronize()
+    assert e.device_errors() == 0 and np.isfinite(float(e.last_loss().item()))
+    e.close()

@@ -446,3 +446,146 @@ def test_cnn_update_in_a_captured_graph(dq):
     assert np.array_equal(host(graphed.get_buffer("mu")), host(eager.get_buffer("mu")))
     del g
     eager.close(); graphed.close()
+
+
+@pytest.mark.parametrize("B", [37, 130])
+def test_cnn_fc_wide_tile_bf16(dq, B):
+    """k_cnn_layer<..., 3, 1> -- the 128 x 128 fc tile (2 x 2 MFMA tiles per wave) the bf16 mode takes
+    from 8 192 rows -- forced at test sizes (dqn_cnn_set_flags(DQN_CNN_FLAG_FC_WIDE_TILE)), ragged in m (37, 130 rows of a
+    128-row tile). Every output element is the same k-ascending chain of v_mfma_f32_32x32x16_bf16 accumulations as in the
+    32 x 32 tile, so Q and every gradient leaf must be BIT-IDENTICAL to the narrow-tile result; against f64: 2e-2 of scale for
+    the forward, 3e-2 per gradient leaf with every ReLU open (the setting of test_cnn_grads_bf16 (a))."""
+    e = dq.CnnEngine(num_actions=A, max_batch=B, precision="bf16")
+    P, frames, targets, isw = grad_case(B, 300 + B)
+    Po, o = P.copy(), 0
+    for name, n in LEAVES[:8]:
+        Po[o:o + n] = 1.0 if name.endswith(".b") else Po[o:o + n] * 0.1
+        o += n
+    e.set_params(P)
+    q_narrow = host(e.forward(frames)).copy()
+    e.set_params(Po)
+    qo = oc.cnn_forward(Po, frames, A)[0]
+    tg = (qo + (targets - oc.cnn_forward(P, frames, A)[0])).astype(np.float32)
+    l_narrow = e.grads(frames, tg, isw); g_narrow = host(e.get_buffer("grad")).copy()
+    e.set_flags(dq._lib.CNN_FLAG_FC_WIDE_TILE)
+    e.set_params(P)
+    q_wide = host(e.forward(frames))
+    assert np.array_equal(q_wide, q_narrow)
+    q64 = onp.cnn_forward(P, frames, A, np.float64)
+    assert np.max(np.abs(q_wide - q64)) <= 2e-2 * np.abs(q64).max()
+    e.set_params(Po)
+    l_wide = e.grads(frames, tg, isw); g_wide = host(e.get_buffer("grad"))
+    assert l_wide == l_narrow and np.array_equal(g_wide, g_narrow)
+    g64, l64 = oc.cnn_grads(Po, frames, tg, isw, A, f64=True)
+    assert abs(l_wide - l64) <= 2e-2 * max(1.0, abs(l64))
+    # being bit-equal, the wide tile is exactly as far from f64 as the narrow one (measured: 2.2e-2 on val.w at B = 37). The f64
+    # bar is put on the leaves the fc tile produces or feeds directly (fc, heads): 3e-2; the convolution leaves upstream have
+    # scales of 3e-5 under these 0.1 x weights (bf16 noise of three more layers: 3e-2 ... 8e-2 at B = 130) and are pinned by
+    # the bit-identity with the narrow tile above
+    for name, (err, scale) in leaf_errors(g_wide, g64).items():
+        assert scale > 0 and (name.startswith("conv") or err <= 3e-2), (name, err, scale)
+    e.close()
+
+
+def test_cnn_configs4_size_512(dq):
+    """BASELINE configs[4]'s per-GPU size -- 512 frame stacks -- checked, not only timed.
+    (a) exact-f32 forward of 512 stacks bit-identical to the C restatement (orc_cnn_forward) and 1e-5 of f64 on a subset;
+    (b) Agent._step from a 512-env frame ring with 3-step returns (dqn_cnn_update_replay) == dqn_cnn_update on the rows
+        dqn_cnn_replay_gather assembles: bit-identical parameters, in both precisions;
+    (c) the bf16 gradient of the 512-row batch against the exact-f32 one: correlation >= 0.97 and rms <= 0.25 per weight
+        leaf (the bars of test_cnn_grads_bf16 (b))."""
+    import torch
+    n, B, n_step, gamma = 512, 512, 3, 0.99
+    rng = np.random.default_rng(512)
+    P, Pt = make_params(61), make_params(62)
+    frames = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+    e = dq.CnnEngine(num_actions=A, max_batch=B, precision="f32")
+    e.set_params(P); e.set_params(Pt, target=True)
+    q = host(e.forward(frames))
+    qc, _ = oc.cnn_forward(P, frames, A)
+    assert np.array_equal(q, qc), np.max(np.abs(q - qc))
+    sub = rng.choice(B, 24, replace=False)
+    assert np.allclose(q[sub], onp.cnn_forward(P, frames[sub], A, np.float64), rtol=1e-5, atol=1e-5)
+    # (b) ring of 5 env steps x 512 envs (step-major), sampled rows whose 3-step window exists
+    steps = 5
+    grads = {}
+    for precision in ("f32", "bf16"):
+        out = {}
+        for mode in ("ring", "rows"):
+            c = dq.CnnEngine(num_actions=A, max_batch=B, precision=precision)
+            c.set_params(P); c.set_params(Pt, target=True)
+            c.set_optimizer(lr=1e-3)
+            c.replay_init(steps * n)
+            r2 = np.random.default_rng(77)
+            for t in range(steps):
+                c.replay_add(r2.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8), r2.integers(0, A, n), r2.standard_normal(n).astype(np.float32),
+                             r2.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8), (r2.random(n) < 0.1).astype(np.float32))
+            idx = np.sort(np.random.default_rng(78).integers(0, (steps - n_step + 1) * n, B)).astype(np.int32)
+            isw = np.random.default_rng(79).uniform(0.3, 1.0, B).astype(np.float32)
+            if mode == "ring":
+                td = torch.empty(B, dtype=torch.float32, device="cuda")
+                loss = c.update_from_replay(idx, isw, gamma, td_abs_out=td, want_loss=True, n_step=n_step, n_envs=n)
+                out["td"] = host(td)
+            else:
+                s, a, r, s2, d = c.replay_gather(idx, n_step=n_step, n_envs=n, gamma=gamma)
+                gn = np.float32(gamma)
+                for _ in range(1, n_step):
+                    gn = np.float32(gn * np.float32(gamma))                # gamma^n as n - 1 f32 products (dqn_cnn_update_replay)
+                loss = c.update(s, a, r, s2, d, isw, float(gn), want_loss=True)
+            torch.cuda.synchronize()
+            out[mode] = (host(c.get_buffer("params")).copy(), loss, host(c.get_buffer("grad")).copy())
+            c.close()
+        df = np.flatnonzero(out["ring"][0] != out["rows"][0])
+        assert df.size == 0, (precision, df.size, df[:8], float(np.abs(out["ring"][0] - out["rows"][0]).max()),
+                              int((out["ring"][2] != out["rows"][2]).sum()), out["ring"][1], out["rows"][1])
+        assert out["ring"][1] == out["rows"][1], precision
+        assert np.isfinite(out["td"]).all() and out["td"].min() >= 0
+        grads[precision] = out["ring"][2]
+    # (c)
+    o = 0
+    for name, cnt in LEAVES:
+        got, ref = grads["bf16"][o:o + cnt].astype(np.float64), grads["f32"][o:o + cnt].astype(np.float64)
+        if name.endswith(".w"):
+            assert np.sqrt(((got - ref) ** 2).mean()) <= 0.25 * np.sqrt((ref ** 2).mean()), name
+            assert np.corrcoef(got, ref)[0, 1] >= 0.97, name
+        o += cnt
+    e.close()
+
+
+def test_cnn_side_stream_ordering_across_calls(dq):
+    """the handle's side stream (target pass, dW kernels, the fc leaf's optimizer step) is forked / joined by
+    events inside each call; pinned here ACROSS calls on a non-default stream: two back-to-back dqn_cnn_update_replay +
+    dqn_cnn_act, no host synchronisation in between, bit for bit against the same sequence with the side stream switched
+    off (DQN_CNN_FLAG_NO_SIDE_STREAM: everything in stream order)."""
+    import torch
+    n, B = 16, 32
+    res = {}
+    for side in (True, False):
+        c = dq.CnnEngine(num_actions=A, max_batch=B, precision="bf16")
+        if not side:
+            c.set_flags(dq._lib.CNN_FLAG_NO_SIDE_STREAM)
+        c.set_params(make_params(71)); c.set_params(make_params(72), target=True)
+        c.set_optimizer(lr=1e-3)
+        c.replay_init(8 * n)
+        r2 = np.random.default_rng(73)
+        for t in range(6):
+            c.replay_add(r2.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8), r2.integers(0, A, n), r2.standard_normal(n).astype(np.float32),
+                         r2.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8), (r2.random(n) < 0.1).astype(np.float32))
+        obs = torch.as_tensor(r2.integers(0, 256, (n, 84, 84, 4), dtype=np.uint8)).cuda()
+        idx1 = torch.as_tensor(np.sort(r2.integers(0, 6 * n, B)).astype(np.int32)).cuda()
+        idx2 = torch.as_tensor(np.sort(r2.integers(0, 6 * n, B)).astype(np.int32)).cuda()
+        isw = torch.as_tensor(r2.uniform(0.3, 1, B).astype(np.float32)).cuda()
+        td1 = torch.empty(B, device="cuda"); td2 = torch.empty(B, device="cuda")
+        acts = []
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            c.update_from_replay(idx1, isw, 0.99, td_abs_out=td1)
+            acts.append(c.act(obs, 0.0, seed=1, ctr=0))
+            c.update_from_replay(idx2, isw, 0.99, td_abs_out=td2)
+            acts.append(c.act(obs, 0.0, seed=1, ctr=1))
+            st.synchronize()
+        res[side] = (host(c.get_buffer("params")).copy(), host(td1).copy(), host(td2).copy(), host(acts[0]).copy(), host(acts[1]).copy())
+        c.close()
+    for x, y in zip(res[True], res[False]):
+        assert np.array_equal(x, y)

@@ -316,6 +316,62 @@ def test_per_sample_regimes_bitexact(dq, L_, fill, B, D):
     e.close()
 
 
+@pytest.mark.parametrize("L_,B,force", [
+    (20, 1 << 20, "auto"),      # B = N: every segment touched, ~half of the positions duplicates
+    (20, 1 << 18, "auto"),      # the sweep point N / B = 4
+    (16, 70001, "auto"),        # ragged, more positions than leaves
+    (20, 1024, "segments"),     # the bench batch forced through the segment kernel: most segments empty
+    (9, 8192, "segments"),      # tree smaller than one segment (L < 11): one workgroup, generic level loop, no top levels
+    (12, 5000, "segments"),     # two segments
+    (20, 1 << 18, "chunks"),    # the wave-per-64-positions kernel at the same point (what r02 measured)
+])
+def test_per_write_back_regimes_bitexact(dq, L_, B, force):
+    """r03 sorted priority write-back (k_per_write_seg + k_per_top_seg: leaf segments rebuilt densely in LDS, coalesced
+    stores, no atomics) against the CPU restatement's touched-path update (p = (|delta| + 1e-6)^0.6, the highest
+    batch position of a duplicate wins, parents = left + right): the WHOLE tree bit for bit after an update (|delta|) and after
+    a direct priority set, and the running max priority through the leaves of rows added afterwards."""
+    import torch
+    D = 4
+    dims = (D, 16, 16, 2)
+    N = 1 << L_
+    flags = {"auto": 0, "segments": dq._lib.FLAG_PW_SEGMENTS, "chunks": dq._lib.FLAG_PW_CHUNKS}[force]
+    e = mk(dq, dims, capacity=N, use_per=True, max_batch=B, flags=flags)
+    cr, ct = oc.CReplay(N, D), oc.CPer(L_)
+    rng = np.random.default_rng(170 + L_)
+    fill = N - 4096 if L_ >= 16 else N - 64
+    for k in range(0, fill, 1 << 16):
+        n = min(1 << 16, fill - k)
+        s = rng.standard_normal((n, D)).astype(np.float32); a = rng.integers(0, 2, n).astype(np.int32)
+        r = rng.standard_normal(n).astype(np.float32); d = rng.random(n) < 0.1
+        slots = cr.add(s, a, r, s, d); ct.add(slots); e.replay_add(s, a, r, s, d)
+        pr = (rng.random(n).astype(np.float32) + np.float32(1e-3)) ** np.float32(0.6)
+        ct.set(slots, pr); e.per_set(slots, pr)
+    tree = lambda: host(e.buffer(dq._lib.BUF_TREE)).view(np.uint32)
+    for it in range(2):
+        _, idx, _ = e.per_sample(B, 0.5, seed=31, ctr=it)
+        ci, _ = ct.sample(cr.size, B, 0.5, 31, it)
+        assert np.array_equal(host(idx), ci) and np.all(np.diff(ci) >= 0)
+        td = (np.abs(rng.standard_normal(B)) * (4.0 if it else 0.5)).astype(np.float32)     # it = 1 raises the running max
+        ct.update(ci, td); e.per_update_sorted(ci, td)
+        torch.cuda.synchronize()
+        assert np.array_equal(tree(), ct.tree.view(np.uint32)), it
+        # rows added now enter at the running max priority
+        n = 48
+        s = rng.standard_normal((n, D)).astype(np.float32)
+        slots = cr.add(s, np.zeros(n, np.int32), np.zeros(n, np.float32), s, np.zeros(n, bool)); ct.add(slots)
+        e.replay_add(s, np.zeros(n, np.int32), np.zeros(n, np.float32), s, np.zeros(n, bool))
+        assert np.array_equal(tree(), ct.tree.view(np.uint32)), ("pmax", it)
+    # direct priority set on sorted positions with duplicates (mode 0)
+    pos = np.sort(rng.integers(0, cr.size, min(B, 1 << 16))).astype(np.int32)
+    pr = (rng.random(pos.size).astype(np.float32) + np.float32(0.01))
+    ct.set(pos, pr); e.per_set_sorted(pos, pr)
+    t = tree()
+    assert np.array_equal(t, ct.tree.view(np.uint32))
+    tf = t.view(np.float32); k = np.arange(1, N)
+    assert np.array_equal(tf[k], tf[2 * k] + tf[2 * k + 1])                  # the invariant the dense rebuild relies on
+    e.close()
+
+
 # ---------------------------------------------------------------------------- policy
 def test_act_parity(dq):
     """compute_action (:67-73) + Agent._policy (q_agent.py:137-141), vectorised"""
