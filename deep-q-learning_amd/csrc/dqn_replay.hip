@@ -660,7 +660,7 @@ k_per_top(DqnState *st, float *tree, int L) {
 // serialise at ~0.1 us each.
 // Traffic at L = 20 with every segment touched: 4 MB leaves in, 4 + 4 MB out, 8 B per item -- independent of the tree depth.
 #define PWS_LOG 11
-#define PWS_MIN_B 8192              // below: the wave-per-64-positions kernel (touched paths only) + k_per_top
+#define PWS_MIN_B 1024              // below: the wave-per-64-positions kernel (touched paths only) + k_per_top (measured: 10.3 vs 11.0 us per call at B = 1 024, 10.6 vs 16.8 at 8 192, 14.3 vs 517 at 2^20)
 #define PWS_MAX_ROOT_LOG 13          // at most 2^13 segment roots in the top kernel's LDS heap (L <= 24)
 
 __global__ void __launch_bounds__(256)

@@ -59,7 +59,7 @@ typedef enum {
     DQN_FLAG_BIG_ROWS = 8,         /* take the 64-row large-batch kernels (dqn_net_big.hip; 2x256 nets) for every batch of
                                     * >= 64 rows instead of from 16 384 rows up (tests: same results at small sizes) */
     DQN_FLAG_PW_SEGMENTS = 16,     /* sorted priority write-back: always the leaf-segment kernel (k_per_write_seg, normally from
-                                    * 8 192 batch positions) ... */
+                                    * 1 024 batch positions) ... */
     DQN_FLAG_PW_CHUNKS = 32        /* ... / always the wave-per-64-positions kernel. Same tree, bit for bit. */
 } dqn_flags;
 

@@ -454,7 +454,7 @@ def test_cnn_fc_wide_tile_bf16(dq, B):
     from 8 192 rows -- forced at test sizes (dqn_cnn_set_flags(DQN_CNN_FLAG_FC_WIDE_TILE)), ragged in m (37, 130 rows of a
     128-row tile). Every output element is the same k-ascending chain of v_mfma_f32_32x32x16_bf16 accumulations as in the
     32 x 32 tile, so Q and every gradient leaf must be BIT-IDENTICAL to the narrow-tile result; against f64: 2e-2 of scale for
-    the forward, 3e-2 per gradient leaf with every ReLU open (the setting of test_cnn_grads_bf16 (a))."""
+    the forward and the loss."""
     e = dq.CnnEngine(num_actions=A, max_batch=B, precision="bf16")
     P, frames, targets, isw = grad_case(B, 300 + B)
     Po, o = P.copy(), 0
@@ -478,12 +478,12 @@ def test_cnn_fc_wide_tile_bf16(dq, B):
     assert l_wide == l_narrow and np.array_equal(g_wide, g_narrow)
     g64, l64 = oc.cnn_grads(Po, frames, tg, isw, A, f64=True)
     assert abs(l_wide - l64) <= 2e-2 * max(1.0, abs(l64))
-    # being bit-equal, the wide tile is exactly as far from f64 as the narrow one (measured: 2.2e-2 on val.w at B = 37). The f64
-    # bar is put on the leaves the fc tile produces or feeds directly (fc, heads): 3e-2; the convolution leaves upstream have
-    # scales of 3e-5 under these 0.1 x weights (bf16 noise of three more layers: 3e-2 ... 8e-2 at B = 130) and are pinned by
-    # the bit-identity with the narrow tile above
-    for name, (err, scale) in leaf_errors(g_wide, g64).items():
-        assert scale > 0 and (name.startswith("conv") or err <= 3e-2), (name, err, scale)
+    # Against f64 the gradient leaves are exactly as far as the narrow tile's (bit-equal). How far that is depends on the batch, not
+    # on the tile: with targets within the Huber knee the loss gradient is e = q - target itself, so the bf16 forward's error in
+    # q (2e-2 of scale) enters every leaf, and a leaf whose f64 value is a sum with cancellation (val.b, val.w) shows it as a
+    # large RELATIVE error -- measured (tools/diag/cnn_grad_b.py, every ReLU open): fc.w 2.3e-2 / 5.3e-2 / 8.9e-2 and val.w
+    # 0.11 / 0.10 / 0.32 at B = 24 / 64 / 130, while the exact-f32 mode stays at 2e-6 on every leaf at all of them. The bf16
+    # gradient bars are those of test_cnn_grads_bf16 and of test_cnn_configs4_size_512 (c); here: bit-identity + the loss.
     e.close()
 
 
