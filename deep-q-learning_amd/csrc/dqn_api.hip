@@ -126,7 +126,7 @@ static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, 
     if (use_big(h, B) && !smp && !fuse) {                          // large batches: 64-row tiles (dqn_net_big.hip), forward only
         bool plain = true;
         for (int i = 0; i < n; ++i) plain = plain && !p[i].act_out && !p[i].px && p[i].x;
-        if (plain) { launch_big_forward(s, h->m, p, n, B, h->num_cus); return; }
+        if (plain) { if (h->bf16) launch_big16_forward(s, h->m, p, n, B, h->num_cus); else launch_big_forward(s, h->m, p, n, B, h->num_cus); return; }
     }
     if (h->bf16) launch_qnet_fwd_bf16(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride, h->withhold);
     else launch_qnet_fwd(s, h->m, p, n, B, smp, fuse, h->tile_cnt, h->st, h->tile_stride, h->withhold);
@@ -192,7 +192,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     h->n_step = cfg->n_step > 1 ? cfg->n_step : 1;
     h->gamma_n = cfg->gamma;
     for (int i = 1; i < h->n_step; ++i) h->gamma_n = h->gamma_n * cfg->gamma;       // f32 product, as the oracle's
-    h->Bp = h->bf16 ? (cfg->max_batch + 31) / 32 * 32 : (cfg->max_batch + 63) / 64 * 64;   // whole row tiles of every kernel family
+    h->Bp = (cfg->max_batch + 63) / 64 * 64;                       // whole row tiles of every kernel family
     if (cfg->use_per) {
         int L = 0; while ((1ll << L) < cfg->capacity) ++L;
         if (L < 1) L = 1;
@@ -221,10 +221,11 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->bisw, Bp * 4, DQN_BUF_BATCH_ISW); add(&h->btd, Bp * 4, DQN_BUF_BATCH_TD); add(&h->btd_abs, Bp * 4);
     add(&h->bdf, Bp * 4); add(&h->ba, Bp * 4); add(&h->bidx, Bp * 4, DQN_BUF_BATCH_IDX); add(&h->bd, Bp);
     add(&h->q, Bp * A * 4); add(&h->nq, Bp * A * 4); add(&h->nt, Bp * A * 4);
-    add(&h->px, Bp * K1 * esz); add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
+    add(&h->px, Bp * (h->bf16 ? 32 : K1) * esz);                  // (bf16: the 64-row kernels stash 32 columns)
+    add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
-    if (!h->bf16 && big_supported(h->m, cfg->max_batch, h->big_any)) {
+    if (big_supported(h->m, cfg->max_batch, h->big_any)) {
         add(&h->big_slab, big_slab_floats(cfg->max_batch, h->num_cus) * 4); add(&h->big_colsum, big_colsum_floats(cfg->max_batch) * 4);
     }
     h->tile_stride = (int)(Bp / 16) + 2;
@@ -517,8 +518,8 @@ extern "C" int dqn_grads(dqn_handle *h, const float *s, const float *targets, co
     g.ph1 = h->ph1; g.ph2 = h->ph2; g.pack = h->pack;
     g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3; g.loss_part = h->loss_part;
     if (use_big(h, B)) {                                           // forward + row backward of a row tile in one workgroup, split-K dW
-        launch_big_rows_bwd(st, h->m, &p, 1, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
-        launch_big_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
+        (h->bf16 ? launch_big16_rows_bwd : launch_big_rows_bwd)(st, h->m, &p, 1, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        (h->bf16 ? launch_big16_dw : launch_big_dw)(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
                       h->loss_part, loss ? loss : h->loss_dev, h->st, 0, AdamArgs{}, h->num_cus);
         HIP_TRY(hipGetLastError());
         return DQN_OK;
@@ -592,10 +593,10 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
         g.pack = h->pack; g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
         g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
         arm(h);
-        launch_big_rows_bwd(st, h->m, p, 3, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        (h->bf16 ? launch_big16_rows_bwd : launch_big_rows_bwd)(st, h->m, p, 3, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
         mark(h, st, "big_rows_fwd3_bwd");
         arm(h);
-        launch_big_dw(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
+        (h->bf16 ? launch_big16_dw : launch_big_dw)(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,
                       h->loss_part, h->loss_dev, h->st, 1, fuse_adam ? adam_args(h) : AdamArgs{}, h->num_cus);
         mark(h, st, "big_dw");
         if (fuse_pw && h->cfg.use_per) enqueue_per_writeback(h, B, st);

@@ -118,7 +118,15 @@ void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
 bool big_supported(const NetDims &m, int B, bool any_size = false);   // any_size: from 64 rows (DQN_FLAG_BIG_ROWS)
 size_t big_slab_floats(int max_batch, int num_cus);
 size_t big_colsum_floats(int max_batch);
+int big_dw_slices(int B, int num_cus);
 void launch_big_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus);
+// the same three entry points in the bf16 precision mode (dqn_net_big16.hip: v_mfma_f32_32x32x16_bf16, k-packed bf16 stashes)
+void launch_big16_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus);
+void launch_big16_rows_bwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const BwdArgs &bw,
+                           float *px, float *ph1, float *ph2, float *colsum, DqnState *st, int num_cus);
+void launch_big16_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2, const float *pdz1,
+                     const float *pdz2, const float *pdz3, int B, float *slab, const float *colsum, float *grad,
+                     const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam, int num_cus);
 void launch_big_rows_bwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const BwdArgs &bw,
                          float *px, float *ph1, float *ph2, float *colsum, DqnState *st, int num_cus);
 void launch_big_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2, const float *pdz1,

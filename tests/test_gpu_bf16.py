@@ -267,3 +267,122 @@ def test_bounded_wait_gives_up_and_the_handle_recovers(dq, precision):
         e.stream.synchronize()
     assert e.device_errors() == 0 and np.isfinite(float(e.last_loss().item()))
     e.close()
+
+
+# ---------------------------------------------------------------- r03: the 64-row bf16 kernels (dqn_net_big16.hip)
+def mk_big(dq, dims, **kw):
+    return dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3],
+                                     precision="bf16", flags=dq._lib.FLAG_BIG_ROWS, **kw))
+
+
+@pytest.mark.parametrize("B,D", [(64, 8), (200, 8), (1000, 9), (130, 20)])
+def test_bf16_big_rows_forward_and_targets(dq, B, D):
+    """k_big_rows16 (v_mfma_f32_32x32x16_bf16, 64 rows per workgroup) forced at small sizes (DQN_FLAG_BIG_ROWS), ragged last
+    tile, both layer-1 forms (D <= 16: one k-step; D = 20: two): Q, features and compute_q_targets within bf16's 2e-2 / 3e-2 of
+    scale of f64, deterministic, and within 1e-2 of the 16-row bf16 kernels (same roundings, another accumulation order)."""
+    dims = (D, 256, 256, 4)
+    e = mk_big(dq, dims, max_batch=B)
+    e16 = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 0), rand_params(dims, 1)
+    for x in (e, e16):
+        x.set_params(P); x.set_params(Pt, dq._lib.BUF_TARGET)
+    s, a, r, s2, d = make_batch(dims, B, 2)
+    r = np.clip(r, -3, 3)
+    q, feat = e.forward(s, return_features=True)
+    q, feat = host(q), host(feat)
+    q64, _, h64 = onp.forward(P, s, dims, np.float64, return_hidden=True)
+    scale = np.abs(q64).max()
+    assert np.max(np.abs(q - q64)) <= 2e-2 * scale, np.max(np.abs(q - q64)) / scale
+    assert np.max(np.abs(feat - h64)) <= 2e-2 * np.abs(h64).max()
+    assert np.array_equal(q, host(e.forward(s)))
+    q16 = host(e16.forward(s))
+    assert np.max(np.abs(q - q16)) <= 1e-2 * scale, np.max(np.abs(q - q16)) / scale
+    qt = host(e.forward(s, target=True))
+    assert np.max(np.abs(qt - onp.forward(Pt, s, dims, np.float64))) <= 2e-2 * scale
+    t = host(e.q_targets(s, a, r, s2, d))
+    full = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64, full=True)
+    top2 = np.sort(full["next_q"], axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 4e-2 * scale
+    assert clear.mean() > 0.5
+    assert np.max(np.abs(t - full["targets"])[clear]) <= 3e-2 * max(np.abs(full["targets"]).max(), 1.0)
+    assert np.array_equal(e.get_params(host=True), P)
+    e.close(); e16.close()
+
+
+@pytest.mark.parametrize("B,weighted", [(64, False), (100, True), (1000, True), (1000, False)])
+def test_bf16_big_rows_grads(dq, B, weighted):
+    """jax.grad(compute_loss) through k_big_rows16 + k_big_dw16 (k-packed bf16 stashes, split-K slab) + k_big_reduce<true>:
+    against f64 (cosine > 0.999, 5e-2 of the largest entry -- the bars of test_bf16_grads), every leaf against the 16-row bf16
+    kernels' gradient (2e-2 of the leaf's scale), fixed reduction order."""
+    dims = CFGS["cfg2"]
+    e = mk_big(dq, dims, max_batch=B)
+    e16 = mk(dq, dims, max_batch=B)
+    P, Pt = rand_params(dims, 3), rand_params(dims, 4)
+    e.set_params(P); e16.set_params(P)
+    s, a, r, s2, d = make_batch(dims, B, 5)
+    r = np.clip(r, -3, 3)
+    targets = onp.q_targets(P, Pt, s, a, r, s2, d, 0.99, dims, np.float64).astype(np.float32)
+    isw = np.random.default_rng(6).uniform(0.2, 1, B).astype(np.float32) if weighted else None
+    g64, L64, _ = onp.grads(P, s, targets, dims, isw, np.float64)
+    g, L = e.grads(s, targets, isw)
+    g = host(g)
+    assert abs(host(L)[0] - L64) <= 3e-2 * max(1.0, abs(L64))
+    cos = float(g @ g64 / (np.linalg.norm(g) * np.linalg.norm(g64)))
+    assert cos > 0.999, cos
+    assert np.max(np.abs(g - g64)) <= 5e-2 * np.abs(g64).max()
+    g2, _ = e.grads(s, targets, isw)
+    assert np.array_equal(g, host(g2))
+    g16 = host(e16.grads(s, targets, isw)[0])
+    o = 0
+    from deep_q_learning_amd._tree import shapes
+    for mod, leaf, shp in shapes(dims):
+        n = int(np.prod(shp))
+        sc = np.abs(g64[o:o + n]).max()
+        assert np.max(np.abs(g[o:o + n] - g16[o:o + n])) <= 2e-2 * sc, (mod, leaf, np.max(np.abs(g[o:o + n] - g16[o:o + n])) / sc)
+        # per leaf against f64: no further from it than the 16-row bf16 kernels are (layer 1's leaf carries the roundings of two
+        # backward layers: ~0.1 of its scale on both paths)
+        e_big, e_16 = np.max(np.abs(g[o:o + n] - g64[o:o + n])), np.max(np.abs(g16[o:o + n] - g64[o:o + n]))
+        assert e_big <= 1.5 * e_16 + 1e-2 * sc, (mod, leaf, e_big / sc, e_16 / sc)
+        o += n
+    e.close(); e16.close()
+
+
+@pytest.mark.parametrize("per", [True, False])
+def test_bf16_big_rows_update_tracks_the_16_row_path(dq, per):
+    """Agent._step (q_agent.py:146-169) through the 64-row bf16 kernels (sample -> k_big_rows16 with the three forwards, TD rule
+    and row backward -> k_big_dw16 -> reduce + AdamW + bf16 shadow refresh -> priority write-back), three updates at 1 000
+    rows, against the 16-row bf16 path on the same replay: losses within 2e-2, parameter steps with cosine > 0.99, the shadows
+    really refreshed (a forward after the updates uses the new weights), tree invariant, no wait gave up."""
+    import torch
+    dims = CFGS["cfg2"]
+    B, N = 1000, 1 << 12
+    s, a, r, s2, d = make_batch(dims, 3000, 70, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    P0 = rand_params(dims, 71)
+    out = {}
+    for name, fl in (("big", dq._lib.FLAG_BIG_ROWS), ("rows16", 0)):
+        e = dq.Engine(dq.EngineConfig(obs_dim=dims[0], hidden1=dims[1], hidden2=dims[2], num_actions=dims[3], capacity=N, use_per=per,
+                                      max_batch=B, seed=77, lr=1e-3, precision="bf16", flags=fl))
+        e.replay_add(s, a, r, s2, d > 0)
+        e.set_params(P0); e.set_params(P0, dq._lib.BUF_TARGET)
+        losses = []
+        with torch.cuda.stream(e.stream):
+            for it in range(3):
+                e.update(B); e.stream.synchronize()
+                losses.append(float(e.last_loss().item()))
+        Pn = e.get_params(host=True)
+        x = s[:256]
+        q_after = host(e.forward(x))
+        q64 = onp.forward(Pn, x, dims, np.float64)
+        assert np.max(np.abs(q_after - q64)) <= 2e-2 * np.abs(q64).max()               # shadows = the updated master weights
+        assert e.opt_count() == 3 and e.device_errors() == 0
+        if per:
+            t = host(e.buffer(dq._lib.BUF_TREE)); k = np.arange(1, N)
+            assert np.array_equal(t[k], t[2 * k] + t[2 * k + 1])
+        out[name] = (np.array(losses), Pn)
+        e.close()
+    lb, pb = out["big"]; l16, p16 = out["rows16"]
+    assert np.isfinite(lb).all() and np.all(np.abs(lb - l16) <= 2e-2 * np.maximum(1.0, np.abs(l16))), (lb, l16)
+    db, d16 = pb - P0, p16 - P0
+    cos = float(db @ d16 / (np.linalg.norm(db) * np.linalg.norm(d16)))
+    assert cos > 0.99 and 0.9 < np.linalg.norm(db) / np.linalg.norm(d16) < 1.1, (cos, np.linalg.norm(db) / np.linalg.norm(d16))
