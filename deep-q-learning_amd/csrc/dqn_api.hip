@@ -593,7 +593,14 @@ static void enqueue_backward(dqn_handle *h, int B, hipStream_t st, bool fuse_ada
         g.pack = h->pack; g.pdz1 = h->pdz1; g.pdz2 = h->pdz2; g.pdz3 = h->pdz3;
         g.td = h->btd; g.td_abs = h->btd_abs; g.isw_out = h->bisw; g.loss_part = h->loss_part;
         arm(h);
-        (h->bf16 ? launch_big16_rows_bwd : launch_big_rows_bwd)(st, h->m, p, 3, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        if (h->bf16) {
+            // bf16: online(s'), target(s') by the forward kernel (two workgroups per CU), their Q rows through HBM (32 B per row)
+            launch_big16_forward(st, h->m, p, 2, B, h->num_cus);
+            mark(h, st, "big_fwd2");
+            g.nq = h->nq; g.nt = h->nt;
+            arm(h);
+            launch_big16_rows_bwd(st, h->m, p + 2, 1, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
+        } else launch_big_rows_bwd(st, h->m, p, 3, B, g, h->px, h->ph1, h->ph2, h->big_colsum, h->st, h->num_cus);
         mark(h, st, "big_rows_fwd3_bwd");
         arm(h);
         (h->bf16 ? launch_big16_dw : launch_big_dw)(st, h->m, h->px, h->ph1, h->ph2, h->pdz1, h->pdz2, h->pdz3, B, h->big_slab, h->big_colsum, h->grad,

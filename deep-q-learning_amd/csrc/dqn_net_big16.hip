@@ -22,110 +22,21 @@
 // is the batch row, loads an operand fragment (8 consecutive rows of its column) as ONE 16-byte piece.
 //
 // Only for hidden1 == hidden2 == 256, obs_dim <= 32 (BASELINE configs[1] net); tolerance of the mode: 2e-2 of scale.
-#include <type_traits>
-#include "dqn_device.h"
-#include "dqn_launch.h"
-#include "dqn_net_common.h"
-#include "dqn_bf16_pack.h"
-#include "dqn_big_reduce.h"
+#include "dqn_net_big16.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-#define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-
-// row of accumulator register r of a 32x32 tile for lane half h (C/D map of every 32x32 MFMA)
-__device__ __forceinline__ int row32b(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-constexpr int HB = BIG_H;               // hidden width
-constexpr int SA = HB + 8;              // LDS row stride (bf16 elements) of the activation image: 528 B
-constexpr int SX = 32 + 8;              // of the input image (32 staged columns)
-constexpr int S3 = 16 + 8;              // of dz3
-
-// acc[rt][ct] (+)= A . W for the wave's 64 rows (rt = 0, 1) and two 32-column tiles ct0, ct0 + 1. A: row-major bf16 LDS image;
-// W: bf16 fragment pack with KQ 32-deep k-blocks. Register ring PF k-blocks deep, straight-line code (see dqn_net_big.hip).
-// ONE_STEP: only the first 16-deep k-step of the (single) block carries data (K <= 16).
-template <int KQ, int PF, bool ONE_STEP>
-struct BigLayer16 {
-    const bf16x8 *pb[2];
-    bf16x8 blo[PF][2], bhi[PF][2];
-    __device__ __forceinline__ void init(const __bf16 *wp, int ct0, int lane) {
-        const int h = lane >> 5, c = lane & 31;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-            pb[ct] = reinterpret_cast<const bf16x8 *>(wp) + (long long)(2 * (ct0 + ct) + (c >> 4)) * KQ * 64 + h * 16 + (c & 15);
-    }
-    __device__ __forceinline__ void prefetch() {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int kq = p < KQ ? p : KQ - 1;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                blo[p][ct] = pb[ct][kq * 64];
-                if constexpr (!ONE_STEP) bhi[p][ct] = pb[ct][kq * 64 + 32];
-            }
-        }
-    }
-    __device__ __forceinline__ void run(const __bf16 *la, int S, int lane, f32x16 (&acc)[2][2]) {
-        const int h = lane >> 5, c = lane & 31;
-        const __bf16 *arow0 = la + c * S + 8 * h, *arow1 = arow0 + 32 * S;
-#pragma unroll
-        for (int kq = 0; kq < KQ; ++kq) {
-            const int p = kq % PF;
-            const bf16x8 a00 = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * kq), a10 = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * kq);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                acc[0][ct] = MFMA32B(a00, blo[p][ct], acc[0][ct]);
-                acc[1][ct] = MFMA32B(a10, blo[p][ct], acc[1][ct]);
-            }
-            if constexpr (!ONE_STEP) {
-                const bf16x8 a01 = *reinterpret_cast<const bf16x8 *>(arow0 + 32 * kq + 16), a11 = *reinterpret_cast<const bf16x8 *>(arow1 + 32 * kq + 16);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    acc[0][ct] = MFMA32B(a01, bhi[p][ct], acc[0][ct]);
-                    acc[1][ct] = MFMA32B(a11, bhi[p][ct], acc[1][ct]);
-                }
-            }
-            if (kq + PF < KQ) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) { blo[p][ct] = pb[ct][(kq + PF) * 64]; bhi[p][ct] = pb[ct][(kq + PF) * 64 + 32]; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-};
-
-__device__ __forceinline__ void zero_acc16(f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-}
-
-struct Big16Pass {
-    const float *x;            // [B][D] f32 rows of this pass
-    const float *params;       // flat f32 params (biases)
-    const __bf16 *pack;        // bf16 fragment packs
-    float *q;                  // [B][A] out or NULL
-};
-
-struct Big16Args {
-    Big16Pass p[3]; int npass; // passes in order; in update / grads form the LAST pass is online(s)
-    float *feat;               // [B][H2] f32 features of the last pass (dddqn.py:32-33) or NULL
-    int do_bwd;
-    BwdArgs g;                 // TD inputs / outputs; pdz1/2/3 (k-packed bf16), loss_part
-    __bf16 *px, *ph1, *ph2;    // k-packed stashes, C = 32 / 256 / 256
-    float *colsum;             // [tiles][2*HB + 16]: per-tile column sums of dz1 | dz2 | dz3 (bias gradients)
-    DqnState *st;
-};
-
-template <bool X16>                      // obs_dim <= 16: layer 1 is one 16-deep k-step
-__global__ void __launch_bounds__(256)
-k_big_rows16(NetDims m, Dims16 d16, Big16Args g, int B) {
+#define PSTAMP(S) do { if (ps == 0) STAMP(1, S); } while (0)
+// Two workgroups per CU (58 KB of LDS, 243 registers each): one's epilogue / barriers / global round trips run beside the other's
+// MFMAs -- measured r03 at B = 2^17, one forward pass: 43.8 us with one workgroup per CU, 30.8 us with two. The 256-register
+// budget holds with the layer-2 ring two k-blocks deep (three: 2 scratch registers, 31.9 us; four: 19, no faster).
+#ifndef BIG16_FWD_WGS_PER_CU
+#define BIG16_FWD_WGS_PER_CU 2
+#endif
+#ifndef BIG16_FWD_PF
+#define BIG16_FWD_PF 2
+#endif
+template <bool X16, bool FEAT>           // obs_dim <= 16: layer 1 is one 16-deep k-step; FEAT: the last pass also writes its features
+__global__ void __launch_bounds__(256, FEAT ? 1 : BIG16_FWD_WGS_PER_CU)
+k_big_fwd16(NetDims m, Dims16 d16, Big16Args g, int B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid0 = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -136,7 +47,6 @@ k_big_rows16(NetDims m, Dims16 d16, Big16Args g, int B) {
     __bf16 *l3 = la + 64 * SA;                         // [64][S3]   dz3
     float *lh = reinterpret_cast<float *>(l3 + 64 * S3);   // [64][16]   heads
     float *lq = lh + 64 * 16;                          // [3][64][16] Q rows of the passes
-    float *lrow = lq + 3 * 64 * 16;                    // [64] per-row loss
     const int ct0 = 2 * wave;                          // this wave's two 32-column tiles
 
     // input rows of a pass: thread (g8 = tid >> 5, cc = tid & 31) takes column cc of the eight rows 8 g8 .. 8 g8 + 7 -- its LDS
@@ -151,282 +61,179 @@ k_big_rows16(NetDims m, Dims16 d16, Big16Args g, int B) {
             if (row < B && cc < m.D) xv[j] = P.x[(long long)row * m.D + cc];
         }
     };
+    STAMP(1, 0);
     x_request(g.p[0], (int)blockIdx.x * 64);
+    // The operands of a pass -- layer-1 fragments, biases, the first BIG16_PF k-blocks of layer 2, the heads' fragments -- are
+    // requested ONE PASS AHEAD, each set into the registers its predecessor has just freed. The pass after the last is the next
+    // tile's first (same arrays again).
+    // Two accumulator orientations (same operands, MFMA arguments swapped):
+    //   T (passes that stash nothing): acc = (A W)^T -- lane = batch row, registers 4g..4g+3 = four consecutive OUTPUT COLUMNS:
+    //     the bf16 LDS image takes them as ONE 8-byte store (16 per lane and layer instead of 64 two-byte ones); the bias is
+    //     per register (16 values per column tile, wave-uniform per lane half);
+    //   N (the stash pass online(s) and the row backward): lane = output column, registers = batch rows: four consecutive rows
+    //     of a column are the 8-byte piece of the k-packed stash; the LDS image takes two-byte stores.
+    const int lane0 = tid0 & 63, c0 = lane0 & 31, h0 = lane0 >> 5;
+    BigLayer16<1, 1, X16> L1; BigLayer16<HB / 32, BIG16_FWD_PF, false> L2;
+    float bn1[2], bn2[2];                              // N form: bias of the lane's column
+    f32x4 bt1[2][4], bt2[2][4];                        // T form: biases of columns 8g + 4h + 0..3 of each column tile
+    bf16x8 wv[HB / 32];                                // the heads' weights
+    float biash = 0.0f;                                // head bias of column lane & 15 (value | advantages)
+    auto req_l1 = [&](const Big16Pass &P) { L1.init(P.pack + d16.p_w1, ct0, lane0); L1.prefetch(); };
+    auto req_l2 = [&](const Big16Pass &P) { L2.init(P.pack + d16.p_w2, ct0, lane0); L2.prefetch(); };
+    auto req_b = [&](const Big16Pass &P, long long o_b, float (&bn)[2], f32x4 (&bt)[2][4]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            bn[ct] = P.params[o_b + 32 * (ct0 + ct) + c0];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) bt[ct][gq] = *reinterpret_cast<const f32x4 *>(P.params + o_b + 32 * (ct0 + ct) + 8 * gq + 4 * h0);
+        }
+    };
+    auto req_wv = [&](const Big16Pass &P) {
+        const bf16x8 *wh = reinterpret_cast<const bf16x8 *>(P.pack + d16.p_wh) + lane0;
+#pragma unroll
+        for (int kq = 0; kq < HB / 32; ++kq) wv[kq] = wh[kq * 64];
+        const int r16 = lane0 & 15;
+        biash = 0.0f;
+        if (r16 == 0) biash = P.params[m.o_bv]; else if (r16 <= A) biash = P.params[m.o_ba + r16 - 1];
+    };
+    req_l1(g.p[0]); req_b(g.p[0], m.o_b1, bn1, bt1); req_b(g.p[0], m.o_b2, bn2, bt2); req_l2(g.p[0]); req_wv(g.p[0]);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * 64;
-    unsigned long long m1 = 0ull, m2 = 0ull;           // ReLU gates of this lane's accumulator elements: bit (rt*2 + ct)*16 + r
     for (int ps = 0; ps < g.npass; ++ps) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                  // opaque per pass (keeps the epilogue addresses out of the outer loops)
         const int lane = tid & 63, h = lane >> 5, c = lane & 31;
         const Big16Pass &P = g.p[ps];
         const bool last = ps == g.npass - 1;
-        const bool stash = last && g.do_bwd;
+        const bool feat_on = FEAT && last;
+        const bool nform = feat_on;                    // (the features go out from the N form)
+        const Big16Pass &NP = last ? g.p[0] : g.p[ps + 1];      // whose operands are requested during this pass
+
         {
             const int g8 = tid >> 5, cc = tid & 31;
             bf16x8 xb;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { xb[j] = (__bf16)xv[j]; lx[(8 * g8 + j) * SX + cc] = xb[j]; }
-            if (stash) *reinterpret_cast<bf16x8 *>(g.px + ((long long)((row0 >> 3) + g8) * 32 + cc) * 8) = xb;
         }
-        float bias1[2], bias2[2];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) { bias1[ct] = P.params[m.o_b1 + 32 * (ct0 + ct) + c]; bias2[ct] = P.params[m.o_b2 + 32 * (ct0 + ct) + c]; }
-        BigLayer16<1, 1, X16> L1; BigLayer16<HB / 32, 4, false> L2;
-        L1.init(P.pack + d16.p_w1, ct0, lane); L1.prefetch();
-        L2.init(P.pack + d16.p_w2, ct0, lane);
-        L2.prefetch();                                 // layer 2's first k-blocks travel behind layer 1
         LDS_BARRIER();
+        PSTAMP(1);
+        int rb = row0;
+        asm volatile("" : "+v"(rb));
+        // N-form epilogue of a 256-wide layer: bias is in the accumulators already
+        auto epi_n = [&](f32x16 (&acc)[2][2], auto feat_tag) {
+            constexpr bool FT = decltype(feat_tag)::value;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int col = 32 * (ct0 + ct) + c;
+                    unsigned short *dst = reinterpret_cast<unsigned short *>(la) + (32 * rt + 4 * h) * SA + col;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const unsigned w0 = relu_pack(acc[rt][ct][4 * gq], acc[rt][ct][4 * gq + 1]);
+                        const unsigned w1 = relu_pack(acc[rt][ct][4 * gq + 2], acc[rt][ct][4 * gq + 3]);
+                        dst[(8 * gq + 0) * SA] = (unsigned short)w0; dst[(8 * gq + 1) * SA] = (unsigned short)(w0 >> 16);
+                        dst[(8 * gq + 2) * SA] = (unsigned short)w1; dst[(8 * gq + 3) * SA] = (unsigned short)(w1 >> 16);
+                        if constexpr (FT) {                                                         // dddqn.py:32-33
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int rl = 32 * rt + 8 * gq + 4 * h + u;
+                                const float v = acc[rt][ct][4 * gq + u];
+                                if (rb + rl < B) g.feat[(long long)(rb + rl) * HB + col] = v > 0.0f ? v : 0.0f;
+                            }
+                        }
+                    }
+                }
+        };
+        // T-form epilogue: lane = batch row 32 rt + c, registers 4g .. 4g+3 = columns 8g + 4h + 0..3 of the column tile
+        auto epi_t = [&](f32x16 (&acc)[2][2]) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    __bf16 *dst = la + (32 * rt + c) * SA + 32 * (ct0 + ct) + 4 * h;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<u32x2v *>(dst + 8 * gq) = u32x2v{relu_pack(acc[rt][ct][4 * gq], acc[rt][ct][4 * gq + 1]),
+                                                                            relu_pack(acc[rt][ct][4 * gq + 2], acc[rt][ct][4 * gq + 3])};
+                }
+        };
+        auto init_n = [&](f32x16 (&acc)[2][2], const float (&bn)[2]) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][ct][r] = bn[ct];
+        };
+        auto init_t = [&](f32x16 (&acc)[2][2], const f32x4 (&bt)[2][4]) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[rt][ct][r] = bt[ct][r >> 2][r & 3];
+        };
         // ---- layer 1: h1 = relu(x @ w1 + b1)                                  dddqn.py:25-26
         {
             f32x16 acc[2][2];
-            zero_acc16(acc);
-            L1.run(lx, SX, lane, acc);
+            if (nform) { init_n(acc, bn1); L1.run(lx, SX, lane, acc); } else { init_t(acc, bt1); L1.run_t(lx, SX, lane, acc); }
+            PSTAMP(2);
+            req_l1(NP);
             if (!last) x_request(g.p[ps + 1], row0);
             else if (tile + (int)gridDim.x < ntiles) x_request(g.p[0], (tile + (int)gridDim.x) * 64);
-            int rb8 = row0 >> 3;
-            asm volatile("" : "+v"(rb8));
-            auto epi1 = [&](auto stash_tag) {
-                constexpr bool ST = decltype(stash_tag)::value;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const int col = 32 * (ct0 + ct) + c;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            bf16x4 pk;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int r = 4 * gq + u;
-                                float v = acc[rt][ct][r] + bias1[ct];
-                                v = v > 0.0f ? v : 0.0f;
-                                pk[u] = (__bf16)v;
-                                la[(32 * rt + row32b(r, h)) * SA + col] = pk[u];
-                                if constexpr (ST) { if (v > 0.0f) m1 |= 1ull << ((rt * 2 + ct) * 16 + r); }
-                            }
-                            if constexpr (ST) *reinterpret_cast<bf16x4 *>(g.ph1 + ((long long)(rb8 + 4 * rt + gq) * HB + col) * 8 + 4 * h) = pk;
-                        }
-                    }
-            };
-            if (stash) epi1(std::true_type{}); else epi1(std::false_type{});
+            if (nform) epi_n(acc, std::false_type{});
+            else epi_t(acc);
+            req_b(NP, m.o_b1, bn1, bt1);
+            PSTAMP(3);
         }
         LDS_BARRIER();
+        PSTAMP(4);
         // ---- layer 2: h2 = relu(h1 @ w2 + b2)                                 dddqn.py:27-28
-        bf16x8 wv[HB / 32];                            // the heads' weights (requested behind layer 2's MFMAs)
         {
             f32x16 acc[2][2];
-            zero_acc16(acc);
-            L2.run(la, SA, lane, acc);
-            {
-                const bf16x8 *wh = reinterpret_cast<const bf16x8 *>(P.pack + d16.p_wh) + lane;
-#pragma unroll
-                for (int kq = 0; kq < HB / 32; ++kq) wv[kq] = wh[kq * 64];
-            }
+            if (nform) { init_n(acc, bn2); L2.run(la, SA, lane, acc); } else { init_t(acc, bt2); L2.run_t(la, SA, lane, acc); }
+            PSTAMP(5);
+            req_l2(NP);
             LDS_BARRIER();                             // every wave has read all of h1: h2 may replace it
-            int rb8 = row0 >> 3, rb = row0;
-            asm volatile("" : "+v"(rb8), "+v"(rb));
-            auto epi2 = [&](auto stash_tag, auto feat_tag) {
-                constexpr bool ST = decltype(stash_tag)::value, FT = decltype(feat_tag)::value;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        const int col = 32 * (ct0 + ct) + c;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            bf16x4 pk;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int r = 4 * gq + u, rl = 32 * rt + row32b(r, h);
-                                float v = acc[rt][ct][r] + bias2[ct];
-                                v = v > 0.0f ? v : 0.0f;
-                                pk[u] = (__bf16)v;
-                                la[rl * SA + col] = pk[u];
-                                if constexpr (FT) { if (rb + rl < B) g.feat[(long long)(rb + rl) * HB + col] = v; }   // :32-33
-                                if constexpr (ST) { if (v > 0.0f) m2 |= 1ull << ((rt * 2 + ct) * 16 + r); }
-                            }
-                            if constexpr (ST) *reinterpret_cast<bf16x4 *>(g.ph2 + ((long long)(rb8 + 4 * rt + gq) * HB + col) * 8 + 4 * h) = pk;
-                        }
-                    }
-            };
-            const bool feat_on = last && g.feat != nullptr;
-            if (stash) { if (feat_on) epi2(std::true_type{}, std::true_type{}); else epi2(std::true_type{}, std::false_type{}); }
-            else { if (feat_on) epi2(std::false_type{}, std::true_type{}); else epi2(std::false_type{}, std::false_type{}); }
+            PSTAMP(6);
+            if (nform) epi_n(acc, std::true_type{});
+            else epi_t(acc);
+            req_b(NP, m.o_b2, bn2, bt2);
+            PSTAMP(7);
         }
         LDS_BARRIER();
-        // ---- heads (dddqn.py:29-30): wave w takes rows 16w .. 16w+15 on 16x16x32 (A: lane (row l&15, k = 8(l>>4) + j))
+        PSTAMP(8);
+        // ---- heads (dddqn.py:29-30): wave w takes rows 16w .. 16w+15 on 16x16x32 (A: lane (row l&15, k = 8(l>>4) + j)), then
+        // its own rows' Q = val + adv - mean(adv) (dddqn.py:31) from its slice of lh: no workgroup barrier in between
         {
             const int kg = lane >> 4, r16 = lane & 15;
             f32x4 hc = {0.f, 0.f, 0.f, 0.f};
             const __bf16 *arow = la + (16 * wave + r16) * SA + 8 * kg;
-            float biash = 0.0f;
-            if (r16 == 0) biash = P.params[m.o_bv]; else if (r16 <= A) biash = P.params[m.o_ba + r16 - 1];
 #pragma unroll
             for (int kq = 0; kq < HB / 32; ++kq) hc = MFMA16B(*reinterpret_cast<const bf16x8 *>(arow + 32 * kq), wv[kq], hc);
+            const float bh = biash;
+            req_wv(NP);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lh[(16 * wave + 4 * kg + r) * 16 + r16] = hc[r] + biash;      // C/D: col l&15, row 4(l>>4) + r
-        }
-        LDS_BARRIER();
-        // ---- Q = val + adv - mean(adv)                                        dddqn.py:31
-        if (tid < 64) {
-            const float *hr = lh + tid * 16;
-            float sum = 0.0f;
-            for (int a = 0; a < A; ++a) sum = sum + hr[1 + a];
-            const float mean = __fdiv_rn(sum, (float)A);
-            for (int a = 0; a < A; ++a) {
-                const float qv = (hr[0] + hr[1 + a]) - mean;
-                lq[(ps * 64 + tid) * 16 + a] = qv;
-                if (P.q && row0 + tid < B) P.q[(long long)(row0 + tid) * A + a] = qv;
-            }
-        }
-        LDS_BARRIER();
-    }
-    if (!g.do_bwd) continue;
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, h = lane >> 5, c = lane & 31;
-
-    // ---- TD target / Huber gradient / dueling backward of this tile's rows (the row arithmetic of k_bwd_rows, f32)
-    const BwdArgs &bw = g.g;
-    const __bf16 *bpack = reinterpret_cast<const __bf16 *>(bw.pack);
-    const int pl = g.npass - 1;                        // pass that produced q = pred
-    BigLayer16<1, 1, true> LA; BigLayer16<HB / 32, 4, false> LB;
-    LA.init(bpack + d16.p_wht, ct0, lane); LA.prefetch();
-    LB.init(bpack + d16.p_w2t, ct0, lane);
-    for (int t = tid; t < 64 * S3; t += 256) l3[t] = (__bf16)0.0f;
-    LDS_BARRIER();
-    if (tid < 64) {
-        const int i = row0 + tid;
-        float rowloss = 0.0f;
-        if (i < B) {
-            float qr[16], tr[16], nqr[16], ntr[16];
-            for (int k2 = 0; k2 < A; ++k2) qr[k2] = lq[(pl * 64 + tid) * 16 + k2];
-            const int ai = bw.a ? bw.a[i] : 0;
-            if (bw.targets) {
-                for (int k2 = 0; k2 < A; ++k2) tr[k2] = bw.targets[(long long)i * A + k2];
-            } else {
-                for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = lq[(0 * 64 + tid) * 16 + k2]; ntr[k2] = lq[(1 * 64 + tid) * 16 + k2]; }
-                const float ri = bw.r[i];
-                const float di = bw.d_f32 ? bw.d_f32[i] : (bw.d_u8[i] ? 1.0f : 0.0f);     // preprocessing :84
-                const float delta = td_row(qr, nqr, ntr, ai, ri, di, bw.gamma, A, tr);
-                if (bw.td) bw.td[i] = delta;
-                if (bw.td_abs) bw.td_abs[i] = fabsf(delta);
-            }
-            float w = 1.0f;
-            if (bw.w_raw) { w = __fdiv_rn(bw.w_raw[i], g.st->wmax); if (bw.isw_out) bw.isw_out[i] = w; }
-            else if (bw.isw) w = bw.isw[i];
-            const float invB = __fdiv_rn(1.0f, (float)B);
-            float gk[16], gsum = 0.0f;
-            for (int k2 = 0; k2 < A; ++k2) {
-                const float e = qr[k2] - tr[k2];                       // pred - target, pred == q   (:35)
-                rowloss = rowloss + huber(e);                          // :36
-                const float cc = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
-                gk[k2] = (w * cc) * invB;                              // dL/dpred
-                gsum = gsum + gk[k2];
-                if (bw.dq) bw.dq[(long long)i * A + k2] = gk[k2];
-                if (bw.targets_out) bw.targets_out[(long long)i * A + k2] = tr[k2];
-            }
-            if (bw.w_raw || bw.isw) rowloss = w * rowloss;
-            const float gmean = __fdiv_rn(gsum, (float)A);             // dueling backward: dv = sum g ; dadv = g - mean g
-            l3[tid * S3 + 0] = (__bf16)gsum;
-            for (int k2 = 0; k2 < A; ++k2) l3[tid * S3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
-        }
-        lrow[tid] = rowloss;
-    }
-    LDS_BARRIER();
-    if (tid == 0) {                                    // per-tile loss, 16-row sub-tiles in order (as the 16-row kernels)
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float s = 0.0f;
-            for (int k = 0; k < 16; ++k) s = s + lrow[16 * q4 + k];
-            bw.loss_part[4 * tile + q4] = s;
-        }
-    }
-    float *cs = g.colsum + (long long)tile * (2 * HB + 16);
-    if (tid < 16) {                                    // column sums of dz3 (the values the weight gradient sees)
-        float s = 0.0f;
-        for (int rl = 0; rl < 64; ++rl) s = s + (float)l3[rl * S3 + tid];
-        cs[2 * HB + tid] = s;
-    }
-    if (tid < 128) {                                   // dz3 out, k-packed [B/8][16][8]: thread (g8, cc) one 16-byte piece
-        const int g8 = tid >> 4, cc = tid & 15;
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = l3[(8 * g8 + j) * S3 + cc];
-        *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(bw.pdz3) + ((long long)((row0 >> 3) + g8) * 16 + cc) * 8) = v;
-    }
-    auto colsum64 = [&](const f32x16 &x0, const f32x16 &x1) -> float {
-        float s = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s = s + x0[r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s = s + x1[r];
-        return s + __shfl_xor(s, 32, 64);
-    };
-    __bf16 *pdz2 = reinterpret_cast<__bf16 *>(bw.pdz2), *pdz1 = reinterpret_cast<__bf16 *>(bw.pdz1);
-    // ---- dz2 = (dz3 . WH^T) * (h2 > 0)
-    {
-        f32x16 acc[2][2];
-        zero_acc16(acc);
-        LB.prefetch();                                 // W2^T's first k-blocks travel behind dz2
-        LA.run(l3, S3, lane, acc);
-        LDS_BARRIER();                                 // (heads / Q are long done with h2: dz2 replaces it)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int col = 32 * (ct0 + ct) + c;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = 4 * gq + u;
-                        const float v = ((m2 >> ((rt * 2 + ct) * 16 + r)) & 1ull) ? acc[rt][ct][r] : 0.0f;
-                        acc[rt][ct][r] = v;
-                        pk[u] = (__bf16)v;
-                        la[(32 * rt + row32b(r, h)) * SA + col] = pk[u];
-                    }
-                    *reinterpret_cast<bf16x4 *>(pdz2 + ((long long)((row0 >> 3) + 4 * rt + gq) * HB + col) * 8 + 4 * h) = pk;
+            for (int r = 0; r < 4; ++r) lh[(16 * wave + 4 * kg + r) * 16 + r16] = hc[r] + bh;      // C/D: col l&15, row 4(l>>4) + r
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the wave's own LDS stores: wave-synchronous)
+            if (lane < 16) {
+                const int rl = 16 * wave + lane;
+                const float *hr = lh + rl * 16;
+                float sum = 0.0f;
+                for (int a = 0; a < A; ++a) sum = sum + hr[1 + a];
+                const float mean = __fdiv_rn(sum, (float)A);
+                for (int a = 0; a < A; ++a) {
+                    const float qv = (hr[0] + hr[1 + a]) - mean;
+                    lq[(ps * 64 + rl) * 16 + a] = qv;
+                    if (P.q && row0 + rl < B) P.q[(long long)(row0 + rl) * A + a] = qv;
                 }
             }
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float s = colsum64(acc[0][ct], acc[1][ct]);
-            if (h == 0) cs[HB + 32 * (ct0 + ct) + c] = s;
+            PSTAMP(9);
         }
+        LDS_BARRIER();
+        PSTAMP(10);
     }
-    LDS_BARRIER();
-    // ---- dz1 = (dz2 . W2^T) * (h1 > 0)
-    {
-        f32x16 acc[2][2];
-        zero_acc16(acc);
-        LB.run(la, SA, lane, acc);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int col = 32 * (ct0 + ct) + c;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = 4 * gq + u;
-                        const float v = ((m1 >> ((rt * 2 + ct) * 16 + r)) & 1ull) ? acc[rt][ct][r] : 0.0f;
-                        acc[rt][ct][r] = v;
-                        pk[u] = (__bf16)v;
-                    }
-                    *reinterpret_cast<bf16x4 *>(pdz1 + ((long long)((row0 >> 3) + 4 * rt + gq) * HB + col) * 8 + 4 * h) = pk;
-                }
-            }
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const float s = colsum64(acc[0][ct], acc[1][ct]);
-            if (h == 0) cs[32 * (ct0 + ct) + c] = s;
-        }
-    }
-    LDS_BARRIER();                                     // the next tile's first pass rewrites the images
     }   // row tiles
 }
 
@@ -539,39 +346,32 @@ static size_t big16_rows_lds() {
     return 2 * (size_t)(64 * SX + 64 * SA + 64 * S3) + 4 * (size_t)(64 * 16 + 3 * 64 * 16 + 64);
 }
 
-static void launch_rows16(hipStream_t s, const NetDims &m, const Big16Args &g, int B, int num_cus) {
-    const int tiles = (B + 63) / 64;
-    const int grid = tiles < 2 * num_cus ? tiles : 2 * num_cus;          // two workgroups per CU
-    const Dims16 d = make_dims16(m);
-    if (m.D <= 16) DQN_LAUNCH((k_big_rows16<true>), dim3(grid), dim3(256), big16_rows_lds(), s, m, d, g, B);
-    else DQN_LAUNCH((k_big_rows16<false>), dim3(grid), dim3(256), big16_rows_lds(), s, m, d, g, B);
-}
-
 void launch_big16_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus) {
     Big16Args g{};
     g.npass = npass;
     for (int i = 0; i < npass; ++i) g.p[i] = Big16Pass{passes[i].x, passes[i].params, reinterpret_cast<const __bf16 *>(passes[i].pack), passes[i].q};
     g.feat = passes[npass - 1].feat;
-    launch_rows16(s, m, g, B, num_cus);
-}
-
-// passes: update form = {online(s'), target(s'), online(s)}; grads form (bw.targets given) = {online(s)}
-void launch_big16_rows_bwd(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, const BwdArgs &bw,
-                           float *px, float *ph1, float *ph2, float *colsum, DqnState *st, int num_cus) {
-    Big16Args g{};
-    g.npass = npass;
-    for (int i = 0; i < npass; ++i) g.p[i] = Big16Pass{passes[i].x, passes[i].params, reinterpret_cast<const __bf16 *>(passes[i].pack), passes[i].q};
-    g.do_bwd = 1; g.g = bw;
-    g.px = reinterpret_cast<__bf16 *>(px); g.ph1 = reinterpret_cast<__bf16 *>(ph1); g.ph2 = reinterpret_cast<__bf16 *>(ph2);
-    g.colsum = colsum; g.st = st;
-    launch_rows16(s, m, g, B, num_cus);
+    const int tiles = (B + 63) / 64;
+    const int grid = tiles < BIG16_FWD_WGS_PER_CU * num_cus ? tiles : BIG16_FWD_WGS_PER_CU * num_cus;
+    const Dims16 d = make_dims16(m);
+    if (g.feat) {
+        const int grid1 = tiles < num_cus ? tiles : num_cus;
+        if (m.D <= 16) DQN_LAUNCH((k_big_fwd16<true, true>), dim3(grid1), dim3(256), big16_rows_lds(), s, m, d, g, B);
+        else DQN_LAUNCH((k_big_fwd16<false, true>), dim3(grid1), dim3(256), big16_rows_lds(), s, m, d, g, B);
+    } else {
+        if (m.D <= 16) DQN_LAUNCH((k_big_fwd16<true, false>), dim3(grid), dim3(256), big16_rows_lds(), s, m, d, g, B);
+        else DQN_LAUNCH((k_big_fwd16<false, false>), dim3(grid), dim3(256), big16_rows_lds(), s, m, d, g, B);
+    }
 }
 
 void launch_big16_dw(hipStream_t s, const NetDims &m, const float *px, const float *ph1, const float *ph2, const float *pdz1,
                      const float *pdz2, const float *pdz3, int B, float *slab, const float *colsum, float *grad,
                      const float *loss_part, float *loss_out, DqnState *st, int bump_ctr, const AdamArgs &adam, int num_cus) {
     const int Bp64 = (B + 63) / 64 * 64;
-    const int KS = big_dw_slices(B, num_cus);
+#ifndef BIG16_DW_SLICE_DIV
+#define BIG16_DW_SLICE_DIV 2                                       // 32 slices: slab 16.7 MB -- reduce 44 -> 24 us, dW 73 -> 82 us at B = 2^17
+#endif
+    const int KS = big_dw_slices(B, num_cus / BIG16_DW_SLICE_DIV);
     int rps = (Bp64 + KS - 1) / KS;
     rps = (rps + 63) / 64 * 64;                                       // whole row tiles per slice (rows >= B carry zero gradients)
     const int ks_used = (Bp64 + rps - 1) / rps;

@@ -17,7 +17,10 @@ ap.add_argument("--mode", default="fwd")
 ap.add_argument("--log2", type=int, default=15)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--precision", default="f32")
+ap.add_argument("--lib", default=None, help="a variant build of the library")
 args = ap.parse_args()
+if args.lib:
+    dq._lib.LIB_PATH = os.path.abspath(args.lib)
 D, H1, H2, A = bench.D, bench.H1, bench.H2, bench.A
 B = 1 << args.log2
 eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << 20, use_per=True, max_batch=B, seed=3,
