@@ -280,16 +280,30 @@ def cpu_baseline(seconds=float(os.environ.get("DQN_BENCH_CPU_SECONDS", "8"))):
     return out
 
 
-def quick_rate(dq, precision, rank, world, steps):
-    """secondary measurement: the same step loop on another precision mode (single GPU only)"""
+def quick_rate(dq, precision, rank, world, steps, obs_wrapper=False):
+    """secondary measurement: the same step loop on another precision mode (single GPU only); obs_wrapper: the reference's
+    own observation shape -- D + 1 = 9 columns, the last one ObsWrapper's step / max_steps (LunarLander/env.py:19-24,
+    max_steps 1 500 as Test/lunar_lander.py:29), kept by the actor kernel"""
     L = dq._lib
-    eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << LOG2N, use_per=True,
+    Dd = D + 1 if obs_wrapper else D
+    eng = dq.Engine(dq.EngineConfig(obs_dim=Dd, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << LOG2N, use_per=True,
                                     max_batch=B, optimizer="adamw", lr=2e-4, gamma=0.99, seed=1000 + rank,
                                     world_size=world, precision=precision))
     gen = torch.Generator(device=eng.device); gen.manual_seed(1234 + rank)
     eng.set_params(init_params(eng.param_count)); eng.sync_target()
-    prefill(eng, gen)
-    eng.env_reset(torch.randn(N_ENVS, D, device=eng.device, generator=gen), P_DONE)
+    if obs_wrapper:
+        N = 1 << LOG2N
+        for k in range(0, N, 1 << 16):
+            n = 1 << 16
+            s = torch.randn(n, Dd, device=eng.device, generator=gen); s[:, Dd - 1] = torch.rand(n, device=eng.device, generator=gen)
+            eng.replay_add(s, torch.randint(0, A, (n,), device=eng.device, generator=gen, dtype=torch.int32), torch.randn(n, device=eng.device, generator=gen),
+                           s.roll(1, 0), torch.rand(n, device=eng.device, generator=gen) < P_DONE)
+        eng.env_config("synthetic", 1500, 1.0); eng.env_time_feature(True)
+        obs0 = torch.randn(N_ENVS, Dd, device=eng.device, generator=gen); obs0[:, Dd - 1] = 0.0
+        eng.env_reset(obs0, P_DONE)
+    else:
+        prefill(eng, gen)
+        eng.env_reset(torch.randn(N_ENVS, D, device=eng.device, generator=gen), P_DONE)
     eng.set_epsilon(0.15)
     st = eng.stream
     n = steps // ITERS_PER_GRAPH
@@ -302,6 +316,11 @@ def quick_rate(dq, precision, rank, world, steps):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     loss = float(eng.last_loss().item())
     eng.close()
+    if obs_wrapper:
+        return {"dtype": precision, "value": n * ITERS_PER_GRAPH / dt, "unit": "grad-updates/sec", "ms_per_step": dt / (n * ITERS_PER_GRAPH) * 1e3,
+                "obs_dim": Dd, "final_loss": loss,
+                "note": "the reference's own shape: 8 observations + ObsWrapper's step / max_steps column (env.py:19-24), kept inside "
+                        "the one-launch actor kernel; same loop as the headline otherwise"}
     return {"dtype": precision, "value": n * ITERS_PER_GRAPH / dt, "unit": "grad-updates/sec",
             "ms_per_step": dt / (n * ITERS_PER_GRAPH) * 1e3, "env_steps_per_sec": n * ITERS_PER_GRAPH * N_ENVS * TRAIN_FREQ / dt,
             "steps": n * ITERS_PER_GRAPH, "final_loss": loss,
@@ -706,6 +725,7 @@ def main():
         if world == 1 and not dp and args.precision == "f32" and not args.no_secondary:
             eng.close()
             out["bf16"] = quick_rate(dq, "bf16", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH))
+            out["obs_wrapper_d9"] = quick_rate(dq, "f32", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH), obs_wrapper=True)
             out["kernels"].update(per_sample_child())
             out["kernels"].update(cnn_lines(dq))
         if world == 1 and not args.no_cpu_baseline:

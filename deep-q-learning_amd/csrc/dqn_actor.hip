@@ -336,12 +336,13 @@ k_actor(NetDims m, ActorArgs g) {
         const int DP = (D + 3) & ~3;
         const int sx = DP + 4, s1 = 16 * KB + 4, s2 = 16 * KB2 + 4;
         float *lx = lds, *l1 = lx + 4 * sx, *l2 = l1 + 4 * s1, *lwh = l2 + 4 * s2, *lq = lwh + (A + 1) * s2;
-        int *lt = reinterpret_cast<int *>(lq + 64);                          // CartPole step counters of the tile
+        int *lt = reinterpret_cast<int *>(lq + 64);                          // step counters of the tile's envs, [2][4]: CartPole uses [0];
+                                                                             // the time feature reads [t & 1] and writes [(t + 1) & 1]
         // Philox draws of TC steps at a time, [TC][4 envs][DW]: the synthetic env's next observation (D floats), then the
         // policy's u, its random action, done, reward. None depends on the forward pass: waves 1..3 make them for a whole
         // chunk of steps up front (behind the W2 stream for the first tile) instead of inside every step.
         const int DO = (D + 3) & ~3, DW = DO + 4;                            // the four scalars sit 16-B aligned behind the observation
-        float *lpart = lq + 64 + 4;                                          // heads: the four waves' partial sums [4][64]
+        float *lpart = lq + 64 + 8;                                          // heads: the four waves' partial sums [4][64]
         float *ldraw = lpart + 256;
         // bf16 mode: bf16 images of h1 / h2 / the heads' weights (rounded ONCE, by the lanes that produce them: a chain link
         // is then one 8-B LDS read + one MFMA, no conversion in its shadow)
@@ -523,7 +524,7 @@ k_actor(NetDims m, ActorArgs g) {
                 const int il = t / sx, el = t - il * sx;
                 lx[t] = (il < cnt && el < D) ? e.env_obs[(long long)(i0 + il) * D + el] : 0.0f;
             }
-            if (e.kind == 1 && tid < 4) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
+            if ((e.kind == 1 || e.time_feature) && tid < 4) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
             LDS_BARRIER();
             ASTAMP(1);
 
@@ -827,6 +828,7 @@ k_actor(NetDims m, ActorArgs g) {
                             }
                         } else {
                             int a_row = act, d_row = dr.z != 0.0f ? 1 : 0;
+                            if constexpr (!NSTEP) { if (e.time_feature && lt[4 * (t & 1) + il] + 1 >= e.max_steps) d_row = 1; }   // q_agent.py:179-180
                             float rew = dr.w;
                             if constexpr (NSTEP) nstep_row(e, ns, hpos, hold, i, emit, a_row, rew, d_row);
                             if (emit) {
@@ -843,7 +845,19 @@ k_actor(NetDims m, ActorArgs g) {
                     for (int u = tid - 64; u < nobs; u += 192) {
                         const int il = u / D, el = u - il * D, i = i0 + il;
                         long long k = at + il; if (k >= e.cap) k -= e.cap;
-                        const float nx = dstep[il * DW + el];
+                        float nx = dstep[il * DW + el], nx_env = nx;
+                        if constexpr (!NSTEP) {
+                            if (e.time_feature && el == D - 1) {
+                                // LunarLander/env.py:19-24: step pre-incremented, feature = float32(step / max_steps) (python float
+                                // division = f64), reset() -> 0; the thread of this column keeps the env's counter
+                                const int tt = lt[4 * (t & 1) + il] + 1;
+                                const bool done = dstep[il * DW + DO + 2] != 0.0f || tt >= e.max_steps;
+                                nx = (float)((double)tt / (double)e.max_steps);
+                                nx_env = done ? 0.0f : nx;
+                                lt[4 * ((t + 1) & 1) + il] = done ? 0 : tt;
+                                if (last) e.env_t[i] = done ? 0 : tt;
+                            }
+                        }
                         float s_row = lx[il * sx + el];
                         if constexpr (NSTEP) {                                            // n-step: the row starts at the oldest step on file
                             e.hist_s[((long long)hpos * e.hist_stride + i) * D + el] = s_row;
@@ -853,8 +867,8 @@ k_actor(NetDims m, ActorArgs g) {
                             e.states[k * D + el] = s_row;                        // replay_buffer.py:59
                             e.observations[k * D + el] = nx;                     // :62
                         }
-                        lx[il * sx + el] = nx;                                   // q_agent.py:183 (read by this thread only)
-                        if (last) e.env_obs[(long long)i * D + el] = nx;
+                        lx[il * sx + el] = nx_env;                               // q_agent.py:183 (read by this thread only)
+                        if (last) e.env_obs[(long long)i * D + el] = nx_env;
                     }
                 }
                 LDS_BARRIER();
@@ -915,8 +929,8 @@ k_actor16(NetDims m, ActorArgs g) {
         const int sx = 16 + 4, sh = 16 * KQ + 4;
         const int DO = (D + 3) & ~3, DW = DO + 4;
         float *lx = lds, *l1 = lx + 16 * sx, *l2 = l1 + 16 * sh, *lh = l2 + 16 * sh;
-        int *lt = reinterpret_cast<int *>(lh + 256);
-        float *ldraw = lh + 256 + 16;
+        int *lt = reinterpret_cast<int *>(lh + 256);                         // [2][16] (see k_actor)
+        float *ldraw = lh + 256 + 32;
         const float *P = g.params;
         const int c15 = lane & 15, g4 = lane >> 4;
         const int KQ2 = H1 / 16, KQH = H2 / 16, CT1 = H1 / 16, CT2 = H2 / 16;
@@ -995,7 +1009,7 @@ k_actor16(NetDims m, ActorArgs g) {
                 const int rl = tid >> 4, c = tid & 15;
                 lx[rl * sx + perm16a(c)] = (rl < cnt && c < D) ? e.env_obs[(long long)(i0 + rl) * D + c] : 0.0f;
             }
-            if (e.kind == 1 && tid < 16) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
+            if ((e.kind == 1 || e.time_feature) && tid < 16) lt[tid] = tid < cnt ? e.env_t[i0 + tid] : 0;
             LDS_BARRIER();
             if (tile == wg) ASTAMP(1);
             if (tile == wg && tid == 0) {                                    // arrival ticket, early (see k_actor): every wave has c0 / ec
@@ -1132,7 +1146,7 @@ k_actor16(NetDims m, ActorArgs g) {
                         } else {
                             e.actions[k] = act;                                      // replay_buffer.py:60
                             e.rewards[k] = dr.w;                                     // :61
-                            e.dones[k] = dr.z != 0.0f ? 1 : 0;                       // :63
+                            e.dones[k] = (dr.z != 0.0f || (e.time_feature && lt[16 * (t & 1) + il] + 1 >= e.max_steps)) ? 1 : 0;   // :63, q_agent.py:179-180
                         }
                     }
                 } else if (e.kind == 0) {
@@ -1140,11 +1154,19 @@ k_actor16(NetDims m, ActorArgs g) {
                     for (int u = tid - 64; u < cnt * D; u += 192) {
                         const int il = u / D, el = u - il * D, i = i0 + il;
                         long long k = at + il; if (k >= e.cap) k -= e.cap;
-                        const float nx = dstep[il * DW + el];
+                        float nx = dstep[il * DW + el], nx_env = nx;
+                        if (e.time_feature && el == D - 1) {                         // LunarLander/env.py:19-24 (see k_actor)
+                            const int tt = lt[16 * (t & 1) + il] + 1;
+                            const bool done = dstep[il * DW + DO + 2] != 0.0f || tt >= e.max_steps;
+                            nx = (float)((double)tt / (double)e.max_steps);
+                            nx_env = done ? 0.0f : nx;
+                            lt[16 * ((t + 1) & 1) + il] = done ? 0 : tt;
+                            if (last) e.env_t[i] = done ? 0 : tt;
+                        }
                         e.states[k * D + el] = lx[il * sx + perm16a(el)];            // replay_buffer.py:59
                         e.observations[k * D + el] = nx;                             // :62
-                        lx[il * sx + perm16a(el)] = nx;                              // q_agent.py:183 (read by this thread only)
-                        if (last) e.env_obs[(long long)i * D + el] = nx;
+                        lx[il * sx + perm16a(el)] = nx_env;                          // q_agent.py:183 (read by this thread only)
+                        if (last) e.env_obs[(long long)i * D + el] = nx_env;
                     }
                 }
                 LDS_BARRIER();
@@ -1210,7 +1232,7 @@ bool launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
         g.TC = 6144 / (16 * DWh);
         if (g.TC > T) g.TC = T;
         if (g.TC < 1) g.TC = 1;
-        size_t lds = sizeof(float) * (16 * 20 + 2 * 16 * (size_t)(16 * KQ + 4) + 256 + 16 + (size_t)g.TC * 16 * DWh);
+        size_t lds = sizeof(float) * (16 * 20 + 2 * 16 * (size_t)(16 * KQ + 4) + 256 + 32 + (size_t)g.TC * 16 * DWh);
         if (g.n_tree) {
             size_t need = sizeof(float) * 64;
             if (lds < need) lds = need;
@@ -1237,7 +1259,7 @@ bool launch_actor_multi(hipStream_t s, const NetDims &m, const EnvArgs &env, int
     const int KB = m.H1 <= 16 ? 1 : (m.H1 <= 32 ? 2 : (m.H1 <= 64 ? 4 : (m.H1 <= 128 ? 8 : 16)));
     const int KB2 = m.H2 <= 64 ? 4 : 16;
     size_t lds = sizeof(float) * (4 * (size_t)(DP + 4) + 4 * (size_t)(16 * KB + 4) + 4 * (size_t)(16 * KB2 + 4) +
-                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 4 + 256);
+                                  (size_t)(m.A + 1) * (16 * KB2 + 4) + 64 + 8 + 256);
     const int DWh = ((m.D + 3) & ~3) + 4;
     g.TC = 6144 / (4 * DWh);                                              // draw buffer: <= 24 KB
     if (g.TC > T) g.TC = T;

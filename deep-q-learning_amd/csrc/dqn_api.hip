@@ -682,6 +682,7 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
     e.dones = h->dones; e.cap = h->cfg.capacity; e.tree = h->cfg.use_per ? h->tree : nullptr; e.Nt = h->Ntree; e.L = h->L;
     e.env_obs = h->env_obs; e.seed = h->cfg.seed; e.p_done = h->p_done; e.n = n_envs;
     e.kind = h->env_kind; e.max_steps = h->env_max_steps; e.env_t = h->env_t; e.term_reward = h->env_term_reward;
+    e.time_feature = h->env_time_feature ? 1 : 0;
     e.rebuild_top = (rebuild_top && h->cfg.use_per) ? 1 : 0;
     e.n_step = h->n_step; e.hist_stride = h->Bp; e.gamma = h->cfg.gamma;
     e.hist_s = h->hist_s; e.hist_r = h->hist_r; e.hist_a = h->hist_a; e.hist_d = h->hist_d;
@@ -692,7 +693,6 @@ static EnvArgs env_args(dqn_handle *h, int n_envs, bool rebuild_top) {
 // resident in registers, the T*n new leaves inserted by a side workgroup, and -- presample_B > 0 -- the stratified PER
 // draw of the update that follows done by further side workgroups once the leaves are in.
 static bool actor_multi_ok(dqn_handle *h, int n_envs, int T) {
-    if (h->env_time_feature) return false;                        // the time-fraction pass runs behind every vector step: enqueue_actor
     return T >= 1 && (long long)T * n_envs <= h->cfg.capacity && actor_multi_supported(h->m, n_envs, T);
 }
 static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st, bool rebuild_top, int presample_B) {
@@ -714,10 +714,7 @@ static bool enqueue_actor_multi(dqn_handle *h, int T, int n_envs, hipStream_t st
 // q_agent.py:176-183 for n_envs device-resident envs, one vector step: k_actor with T = 1 (forward + epsilon-greedy policy +
 // env transition + ring insert per 4-env workgroup, leaves inserted by the tree workgroup)
 static void enqueue_actor(dqn_handle *h, int n_envs, hipStream_t st, bool rebuild_top = false) {
-    enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0);
-    if (h->env_time_feature)                                      // LunarLander/env.py:19-24 for the vector envs (dqn_env_time_feature)
-        launch_env_time_feature(st, h->st, h->observations, h->dones, h->env_obs, h->env_t, h->cfg.capacity, h->cfg.obs_dim, n_envs,
-                                h->env_max_steps);
+    enqueue_actor_multi(h, 1, n_envs, st, rebuild_top, 0);      // (ObsWrapper's time-fraction column: kept inside the kernel, r03)
 }
 
 // capture `body` into an executable graph on the caller's stream (non-null streams only). body_err: set non-zero by a body

@@ -149,8 +149,6 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
                        unsigned long long seed, unsigned long long ctr, int from_state,
                        float *s, int32_t *a, float *r, float *s2, uint8_t *d, int32_t *idx, float *w_raw,
                        unsigned int *wmax_bits, int num_cus, bool nt_out);
-void launch_env_time_feature(hipStream_t st_, const DqnState *st, float *observations, uint8_t *dones, float *env_obs,
-                             int32_t *env_t, long long cap, int D, int n, int max_steps);
 // pw_part: 8 192 floats of scratch for the segment kernel (k_per_write_seg, large batches); force: 0 = by batch size,
 // 1 = always the wave-per-chunk kernel, 2 = always the segment kernel (tests)
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,

@@ -136,6 +136,8 @@ struct EnvArgs {            // q_agent.py:177-183 on device-resident synthetic e
     int kind;               // 0: synthetic transitions; 1: CartPole-v1 physics
     int max_steps;          // episode truncation (q_agent.py:179-180)
     int32_t *env_t;         // per-env step counter
+    int time_feature;       // ObsWrapper (LunarLander/env.py:19-24): the LAST observation column is step / max_steps, kept by the
+                            // actor kernels themselves (synthetic env, one-step returns); the episode also ends at max_steps
     float term_reward;      // CartPole: reward of the step that terminates the episode (gym: 1; see dqn_env_config)
     int rebuild_top;        // the surplus tree workgroup first rebuilds the dense top of the tree (deferred k_per_top)
     // n-step returns (dqn_config.n_step > 1; k_actor only): per-env history of the last n_step steps, [n_step][hist_stride]

@@ -797,34 +797,6 @@ k_per_add(const DqnState *st, float *tree, long long Nt, int L, int n, long long
 }
 
 
-// ----------------------------------------------- ObsWrapper's time-fraction feature for the vector envs
-// LunarLander/env.py:19-24: the observation handed to the agent is append(obs, step / max_steps) (python float division,
-// then float32), `step` pre-incremented by step() and zeroed by reset(); q_agent.py:179-180 ends the episode at max_steps.
-// The device-resident vector envs keep that feature as the LAST observation column. This pass runs right behind a
-// one-step actor launch (which treated the column like any other): for env i, whose transition went to ring slot
-// (ring_counter - n + i) % capacity, it writes the next observation's feature, folds the step limit into `done`, and sets
-// the env's current feature (0 after an episode end: reset()) and step counter.
-__global__ void __launch_bounds__(256)
-k_env_time_feature(const DqnState *st, float *observations, uint8_t *dones, float *env_obs, int32_t *env_t, long long cap,
-                   int D, int n, int max_steps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long c0 = st->ring_counter - (unsigned long long)n;
-    const long long k = (long long)((c0 + (unsigned long long)i) % (unsigned long long)cap);
-    const int tt = env_t[i] + 1;                                                   // env.py:24
-    const bool done = dones[k] != 0 || tt >= max_steps;                           // q_agent.py:179-180
-    const float f = (float)((double)tt / (double)max_steps);                      // env.py:20
-    observations[k * D + D - 1] = f;
-    dones[k] = done ? 1 : 0;
-    env_obs[(long long)i * D + D - 1] = done ? 0.0f : f;                          // env.py:28-30: reset() -> step 0
-    env_t[i] = done ? 0 : tt;
-}
-
-void launch_env_time_feature(hipStream_t st_, const DqnState *st, float *observations, uint8_t *dones, float *env_obs,
-                             int32_t *env_t, long long cap, int D, int n, int max_steps) {
-    hipLaunchKernelGGL(k_env_time_feature, dim3((n + 255) / 256), dim3(256), 0, st_, st, observations, dones, env_obs, env_t, cap, D, n, max_steps);
-}
-
 // --------------------------------------------------------------------- launchers
 void launch_replay_add(hipStream_t st_, DqnState *st, float *states, int32_t *actions, float *rewards,
                        float *observations, uint8_t *dones, long long N, int D, const float *s,

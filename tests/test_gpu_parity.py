@@ -510,7 +510,8 @@ def test_actor_step_bitexact(dq, per):
 
 @pytest.mark.parametrize("dims,n,max_steps,per", [((9, 32, 64, 4), 37, 5, True), ((9, 256, 256, 4), 256, 7, True), ((9, 32, 64, 4), 64, 1500, False)])
 def test_actor_time_feature_bitexact(dq, dims, n, max_steps, per):
-    """ObsWrapper (LunarLander/env.py:19-31) for the device-resident vector envs (dqn_env_time_feature): the last observation
+    """ObsWrapper (LunarLander/env.py:19-31) for the device-resident vector envs (dqn_env_time_feature; r03: inside the
+    multi-step actor launch -- the reference's own D = 9 shape takes the one-launch actor): the last observation
     column is float32(float64(step) / max_steps), `step` pre-incremented per env step and zeroed at an episode end, and an
     episode also ends at max_steps (q_agent.py:179-180). Ring, env observations, step counters, tree and the captured
     training loop's rows against the restatement, bit for bit, over several truncations (max_steps 5 / 7) and ring wraps;
@@ -534,13 +535,16 @@ def test_actor_time_feature_bitexact(dq, dims, n, max_steps, per):
     steps = 13
     seen = set()
     with torch.cuda.stream(e.stream):
-        for it in range(steps):
-            ctr = lrn.actor_step_tf(obs, t, 0.3, 0.05, max_steps, ctr)
-            seen.update(np.unique(t).tolist())
-            if it % 3 == 2:
-                e.actor_steps(1)                                            # the multi-step entry point falls back to single steps
-            else:
+        # r03: the column is kept INSIDE the actor kernels (k_actor / k_actor16): T vector steps in one launch, truncations and
+        # counter resets in the middle of a launch included (max_steps 5 / 7 against T = 4)
+        for T in (4, 1, 4, 3, 1):                                           # 13 vector steps
+            for _ in range(T):
+                ctr = lrn.actor_step_tf(obs, t, 0.3, 0.05, max_steps, ctr)
+                seen.update(np.unique(t).tolist())
+            if T == 1:
                 e.actor_step()
+            else:
+                e.actor_steps(T)
         e.stream.synchronize()
     L = dq._lib
     assert e.replay_size() == (cr.size, cr.rb.counter)

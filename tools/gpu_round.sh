@@ -26,7 +26,7 @@ print("wall", d["wall_clock"])
 print("roofline", {k: d["roofline"][k] for k in ("achieved", "frac", "avg_us", "kernel")})
 for k, v in d["kernels"].items():
     print(" ", k, round(v["avg_us"], 2), "us", round(v["achieved"], 2), v["unit"], round(v["frac"], 4), {x: round(v[x]) for x in ("updates_per_sec", "env_steps_per_sec") if x in v} or "")
-print("bf16", d.get("bf16", {}).get("value"))
+print("bf16", d.get("bf16", {}).get("value"), "obs_wrapper_d9", d.get("obs_wrapper_d9", {}).get("value"))
 cb = d.get("cpu_baseline", {})
 print("cpu", cb.get("value"), cb.get("cores"), cb.get("one_thread", {}).get("value"), cb.get("torch_cpu", {}).get("value"))
 PY
