@@ -340,6 +340,88 @@ def init_params(n_params):
     return P0
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT touching the HIP / ROCr runtime (the parent of the rank processes must not initialise
+    the GPU): the KFD topology in sysfs (nodes with SIMDs are GPUs), narrowed by the *_VISIBLE_DEVICES lists the launcher set."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(root, node, "properties")) if len(ln.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                pass
+    except OSError:
+        n = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            n = min(n, listed) if n else listed
+    return n
+
+
+def cnn_dp_line(dq, rank, world, dist):
+    """BASELINE configs[4] in its multi-GPU form: every rank a full CNN learner on its own minibatch of 512 frame
+    stacks, ONE gradient exchange per update on the handle's own RCCL communicator -- the 6.4 MB fc leaf on the side stream
+    beside the rest of the backward, the 0.3 MB of small leaves behind it -- AdamW with grad_scale = 1 / world. The communicator
+    is first checked against torch.distributed's all-reduce; any failure on any rank drops the line on every rank."""
+    Bc, A_ = 512, 6
+    flop = 2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7)
+    bwd = 2 * (2 * (81 * 64 * 512 + 49 * 64 * 576 + 3136 * 512 + 512 * 7) + 400 * 32 * 256)
+    ok, e = 1, None
+    try:
+        e = dq.CnnEngine(num_actions=A_, max_batch=Bc, precision="bf16")
+        P = torch.randn(e.param_count, generator=torch.Generator().manual_seed(3)) * 0.02          # same on every rank
+        e.set_params(P); e.set_params(P, target=True)
+        e.comm_init_native()
+        g = e.buffer("grad")
+        probe = (torch.arange(e.param_count, device=e.device, dtype=torch.float32) % 251) * (1.0 + rank)
+        g.copy_(probe); e.allreduce_grads(); torch.cuda.synchronize()
+        want = probe.clone(); dist.all_reduce(want)
+        ok = int(torch.allclose(g, want, rtol=1e-6, atol=0.0) and e.comm_ranks() == world)
+    except Exception as ex:                                   # noqa: BLE001
+        print(f"[bench] CNN communicator unavailable on rank {rank}: {ex}", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if e is not None:
+            e.close()
+        return {}
+    gen = torch.Generator(device="cuda"); gen.manual_seed(70 + rank)
+    fr = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda", generator=gen)
+    fr2 = torch.randint(0, 256, (Bc, 84, 84, 4), dtype=torch.uint8, device="cuda", generator=gen)
+    act = torch.randint(0, A_, (Bc,), dtype=torch.int32, device="cuda", generator=gen)
+    r = torch.randn(Bc, device="cuda", generator=gen); d = (torch.rand(Bc, device="cuda", generator=gen) < 0.05).float()
+    for _ in range(5):
+        e.update(fr, act, r, fr2, d)
+    reps = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); dist.barrier(); e0.record()
+        for _ in range(10):
+            e.update(fr, act, r, fr2, d)
+        e1.record(); e1.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / 10], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps.append(float(t.item()))
+    same = e.get_buffer("params")
+    lo, hi = same.clone(), same.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    identical = bool(torch.equal(lo, hi))
+    e.close()
+    us = float(np.median(reps))
+    fl = (3 * flop + bwd) * Bc * world
+    return {f"cnn_update_dp_B{Bc}_bf16": {"bound": "mfma", "avg_us": us, "launches_per_step": 0, "achieved": fl / us / 1e6,
+                                          "peak": MFMA_BF16_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": fl / us / 1e6 / (MFMA_BF16_PEAK_TFLOPS * world),
+                                          "traffic": None, "updates_per_sec_all_ranks": world * 1e6 / us, "replicas_identical": identical,
+                                          "allreduce_bytes_per_rank": 4 * 1687719,
+                                          "note": "BASELINE configs[4] per-GPU learners: Agent._step on 512 frame stacks per rank, gradient all-reduce on the "
+                                                  "handle's RCCL communicator (fc leaf beside the backward), MAX over ranks, median of 5 regions of 10"}}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher environment: start the N rank processes ourselves, as CHILDREN created
     before this process has made any GPU call (never an exec of a process that touched the GPU), relay rank 0's single
@@ -347,7 +429,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     if os.environ.get("DQN_BENCH_SPAWN_SELFTEST") != "1":
-        have = torch.cuda.device_count()                      # counts devices without initialising the GPU
+        have = visible_gpu_count()                            # sysfs / environment only: no HIP or ROCr call in the parent
         if have < args.gpus:
             print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
             return 3
@@ -661,6 +743,15 @@ def main():
     dev_err = eng.device_errors()
     assert dev_err == 0, f"in-kernel hand-over timed out {dev_err} time(s)"
 
+    # N > 1: the CNN learners' data-parallel update (every rank takes part; rank 0 reports it under "kernels")
+    cnn_dp = {}
+    if world > 1 and not args.no_secondary and os.environ.get("DQN_BENCH_CNN_DP", "1") == "1":
+        try:
+            cnn_dp = cnn_dp_line(dq, rank, world, dist)
+        except Exception as ex:                               # noqa: BLE001 -- the headline line must still be printed
+            print(f"[bench] cnn_update_dp failed on rank {rank}: {ex}", file=sys.stderr)
+            cnn_dp = {}
+
     if rank == 0:
         per_step = {}
         for name, v in kern.items():
@@ -722,6 +813,8 @@ def main():
             "roofline": roof,
             "kernels": per_step,
         }
+        if cnn_dp:
+            out["kernels"].update(cnn_dp)
         if world == 1 and not dp and args.precision == "f32" and not args.no_secondary:
             eng.close()
             out["bf16"] = quick_rate(dq, "bf16", rank, world, max(args.steps // 2, 10 * ITERS_PER_GRAPH))

@@ -86,6 +86,9 @@ SIGNATURES = {
     "dqn_cnn_create": [_I32, _I32, _I32, C.POINTER(_P)],
     "dqn_cnn_destroy": [_P],
     "dqn_cnn_set_flags": [_P, _I32],
+    "dqn_cnn_comm_init": [_P, _P, _I32, _I32],
+    "dqn_cnn_comm_count_host": [_P, C.POINTER(_I32)],
+    "dqn_cnn_allreduce_grads": [_P, _I32, _P],
     "dqn_cnn_param_count": [_P, C.POINTER(_I64)],
     "dqn_cnn_set_params": [_P, C.c_int, _P, C.c_int, _P],
     "dqn_cnn_forward": [_P, C.c_int, _P, _I32, _P, _P],

@@ -33,6 +33,31 @@ class CnnEngine:
         """diagnostics (tests): _lib.CNN_FLAG_FC_WIDE_TILE | CNN_FLAG_NO_SIDE_STREAM; results stay bit-identical"""
         L.check(self.lib.dqn_cnn_set_flags(self.h, int(flags)))
 
+    def comm_init_native(self):
+        """the handle's own RCCL communicator (dqn_cnn_comm_init), as Engine.comm_init_native: rank 0 makes the unique id,
+        torch.distributed carries it to the other ranks. Afterwards update() / update_from_replay() all-reduce the gradient."""
+        import torch.distributed as dist
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            L.check(self.lib.dqn_comm_unique_id(uid))
+        if world > 1:
+            dev = self.device if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor(list(uid.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+        L.check(self.lib.dqn_cnn_comm_init(self.h, uid, rank, world))
+
+    def comm_ranks(self) -> int:
+        n = C.c_int32()
+        L.check(self.lib.dqn_cnn_comm_count_host(self.h, C.byref(n)))
+        return n.value
+
+    def allreduce_grads(self, fc_leaf_done=False):
+        """in-place SUM all-reduce of the "grad" buffer over the handle's communicator (between grads() and
+        optimizer_step(grad_scale=1 / world))"""
+        L.check(self.lib.dqn_cnn_allreduce_grads(self.h, int(bool(fc_leaf_done)), self._s()))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.dqn_cnn_destroy(self.h)

@@ -967,6 +967,28 @@ static int load_rccl() {
     return DQN_OK;
 }
 
+// the same library for the CNN handle's communicator (dqn_cnn.hip): thin wrappers so that one dlopen serves both
+int dqn_rccl_comm_init(void **comm, const void *unique_id_128, int rank, int world) {
+    int rc = load_rccl(); if (rc) return rc;
+    NcclId id;
+    memcpy(&id, unique_id_128, 128);
+    const int e = g_rccl.CommInitRank(comm, world, id, rank);
+    if (e) return fail(DQN_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}
+int dqn_rccl_allreduce_sum_f32(void *comm, float *buf, size_t n, hipStream_t st) {
+    const int e = g_rccl.AllReduce(buf, buf, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, st);
+    if (e) return fail(DQN_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}
+void dqn_rccl_comm_destroy(void *comm) { if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm); }
+int dqn_rccl_comm_count(void *comm, int *n) {
+    if (!g_rccl.CommCount) return fail(DQN_ERR_COMM, "librccl.so lacks ncclCommCount");
+    const int e = g_rccl.CommCount(comm, n);
+    if (e) return fail(DQN_ERR_COMM, "ncclCommCount: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return DQN_OK;
+}
+
 extern "C" int dqn_comm_unique_id(void *unique_id_128) {
     REQUIRE(unique_id_128, "null argument");
     int rc = load_rccl(); if (rc) return rc;

@@ -942,6 +942,8 @@ struct dqn_cnn_handle {
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
     int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
+    void *comm = nullptr; int rank = 0, world = 1;     // dqn_cnn_comm_init: per-GPU learners, one gradient all-reduce per update
+    hipEvent_t ev_fc = nullptr;                        // the fc leaf's all-reduce on the side stream (data-parallel update)
 };
 
 struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
@@ -1042,6 +1044,8 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (!h) return DQN_OK;
     (void)hipDeviceSynchronize();
     if (h->side_kept) h->side = h->side_kept;
+    dqn_rccl_comm_destroy(h->comm);
+    if (h->ev_fc) (void)hipEventDestroy(h->ev_fc);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -1213,7 +1217,7 @@ static void launch_bwd_data(dqn_cnn_handle *h, hipStream_t s, int B) {
 // returns true when the fc weight leaf has been stepped already (prep_opt: dqn_cnn_update; only then)
 template <typename TC>
 static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float *q, const float *targets, const float *isw, int B, hipStream_t s, bool prep_opt,
-                           const CnnTdArgs &td = CnnTdArgs{}) {
+                           const CnnTdArgs &td = CnnTdArgs{}, int *fc_reduced = nullptr) {
     const int blocks = (B + 15) / 16;
     hipLaunchKernelGGL((k_cnn_head_bwd<TC>), dim3(blocks), dim3(256), 0, s, q, targets, isw, (const TC *)h->act[3], h->wh[0], h->A, B, (TC *)h->dz[3], h->hslab, h->hbslab,
                        h->loss_part, td);
@@ -1237,6 +1241,12 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
         hipLaunchKernelGGL((k_cnn_fc_leaf<TC, true>), dim3((3136 / 64) * (512 / 64)), dim3(256), 0, sd, cnn_offs(h), (TC *)h->wt[0][3], (TC *)h->wb[0][3], h->opt, h->params[0], h->grad,
                            h->mu, h->nu, h->adamw, h->b1, h->b2, h->eps, h->wd, 1.0f);
         fc_done = true;
+    }
+    // data-parallel learners: the fc weight leaf is 95 % of the gradient (6.4 MB) and final here (one slice: its dW kernel wrote it
+    // straight into the gradient buffer) -- its all-reduce is issued NOW on the side stream, so that the message whose xGMI
+    // bandwidth matters travels beside conv3 / conv2 / conv1's backward; the small leaves follow after the reduction
+    if (fc_reduced && h->comm && h->world > 1 && h->side && dw_slices(h, 3, B) == 1) {
+        if (dqn_rccl_allreduce_sum_f32(h->comm, h->grad + h->L[3].o_w, (size_t)h->L[3].K * h->L[3].N, sd) == DQN_OK) *fc_reduced = 1;
     }
     launch_dw<TC, TC, 2>(h, sd, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
     launch_bwd_data<TC, 2>(h, s, B);
@@ -1312,6 +1322,39 @@ extern "C" int dqn_cnn_train_step(dqn_cnn_handle *h, const uint8_t *frames, cons
  * the activations of the online pass over s (the fourth forward of the reference's two separate jits is the same numbers),
  * Adam / AdamW. loss_host optional; td_abs_out (device, B floats, optional) = |delta| of q_learning_functions.py:58 per sample
  * (the priorities a PER write-back wants). */
+/* Per-GPU learners: the handle's own RCCL communicator (one process per GPU; unique id from dqn_comm_unique_id on rank 0, carried
+ * to the other ranks by the caller, e.g. torch.distributed). With it dqn_cnn_update / dqn_cnn_update_replay all-reduce the gradient
+ * (sum) before the optimizer and scale it by 1 / world. */
+extern "C" int dqn_cnn_comm_init(dqn_cnn_handle *h, const void *unique_id_128, int32_t rank, int32_t world) {
+    CNN_REQ(h && unique_id_128 && world >= 1 && rank >= 0 && rank < world, "dqn_cnn_comm_init: bad argument");
+    CNN_REQ(!h->comm, "the handle has a communicator already");
+    int rc = dqn_rccl_comm_init(&h->comm, unique_id_128, rank, world); if (rc) return rc;
+    h->rank = rank; h->world = world;
+    if (!h->ev_fc) (void)hipEventCreateWithFlags(&h->ev_fc, hipEventDisableTiming);
+    return DQN_OK;
+}
+extern "C" int dqn_cnn_comm_count_host(dqn_cnn_handle *h, int32_t *ranks) {
+    CNN_REQ(h && ranks, "null argument");
+    *ranks = 0;
+    if (!h->comm) return DQN_OK;
+    int n = 0;
+    int rc = dqn_rccl_comm_count(h->comm, &n); if (rc) return rc;
+    *ranks = n;
+    return DQN_OK;
+}
+/* In-place SUM all-reduce of the gradient buffer (DQN_BUF_GRAD) over the communicator's ranks. fc_leaf_done != 0: the fc weight
+ * leaf has been reduced already (the data-parallel update issues it beside the backward): the two ranges around it follow here.
+ * Between dqn_cnn_grads and dqn_cnn_optimizer_step(grad_scale = 1 / world) call it with fc_leaf_done = 0. */
+extern "C" int dqn_cnn_allreduce_grads(dqn_cnn_handle *h, int32_t fc_leaf_done, void *stream) {
+    CNN_REQ(h, "null handle");
+    if (!h->comm) return dqn_set_error(DQN_ERR_STATE, "dqn_cnn_allreduce_grads before dqn_cnn_comm_init");
+    hipStream_t st = (hipStream_t)stream;
+    if (!fc_leaf_done) return dqn_rccl_allreduce_sum_f32(h->comm, h->grad, (size_t)h->P, st);
+    const long long lo = h->L[3].o_w, hi = lo + (long long)h->L[3].K * h->L[3].N;
+    int rc = dqn_rccl_allreduce_sum_f32(h->comm, h->grad, (size_t)lo, st); if (rc) return rc;
+    return dqn_rccl_allreduce_sum_f32(h->comm, h->grad + hi, (size_t)(h->P - hi), st);
+}
+
 static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
                            const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream) {
     CNN_REQ(h && s && a && r && s2 && d, "null argument");
@@ -1326,6 +1369,18 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     if (h->side) (void)hipStreamWaitEvent(st, h->ev_tgt, 0);
     // the TD rule (:55-60) is the first thing the head-backward kernel does with the three Q tensors
     const CnnTdArgs td{h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, gamma, td_abs_out};
+    if (h->comm) {
+        // per-GPU learners: backward without the early fc-leaf step, the gradient summed over the ranks (fc leaf beside
+        // the backward, the rest behind it), then the optimizer with grad_scale = 1 / world
+        int fc_reduced = 0;
+        if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], nullptr, isw, B, st, false, td, &fc_reduced); else cnn_backward_t<float>(h, s, h->q[0], nullptr, isw, B, st, false, td, &fc_reduced);
+        CNN_TRY(hipGetLastError());
+        rc = dqn_cnn_allreduce_grads(h, fc_reduced, stream); if (rc) return rc;
+        hipLaunchKernelGGL(k_cnn_opt_prep, dim3(1), dim3(1), 0, st, h->opt, h->b1, h->b2);      // step counters (the single-learner route does it beside the backward)
+        rc = cnn_adam(h, 1.0f / (float)h->world, st, false); if (rc) return rc;
+        if (loss_host) { CNN_TRY(hipMemcpyAsync(loss_host, h->loss, 4, hipMemcpyDeviceToHost, st)); CNN_TRY(hipStreamSynchronize(st)); }
+        return DQN_OK;
+    }
     const bool fc_done = h->bf16 ? cnn_backward_t<__bf16>(h, s, h->q[0], nullptr, isw, B, st, true, td) : cnn_backward_t<float>(h, s, h->q[0], nullptr, isw, B, st, true, td);
     CNN_TRY(hipGetLastError());
     rc = cnn_adam(h, 1.0f, st, fc_done); if (rc) return rc;

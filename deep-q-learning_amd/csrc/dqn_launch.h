@@ -119,6 +119,11 @@ bool big_supported(const NetDims &m, int B, bool any_size = false);   // any_siz
 size_t big_slab_floats(int max_batch, int num_cus);
 size_t big_colsum_floats(int max_batch);
 int big_dw_slices(int B, int num_cus);
+// RCCL through the one dlopen'd library of dqn_api.hip (used by the CNN handle's communicator, dqn_cnn.hip)
+int dqn_rccl_comm_init(void **comm, const void *unique_id_128, int rank, int world);
+int dqn_rccl_allreduce_sum_f32(void *comm, float *buf, size_t n, hipStream_t st);
+void dqn_rccl_comm_destroy(void *comm);
+int dqn_rccl_comm_count(void *comm, int *n);
 void launch_big_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus);
 // the same three entry points in the bf16 precision mode (dqn_net_big16.hip: v_mfma_f32_32x32x16_bf16, k-packed bf16 stashes)
 void launch_big16_forward(hipStream_t s, const NetDims &m, const FwdPass *passes, int npass, int B, int num_cus);

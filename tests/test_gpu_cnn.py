@@ -589,3 +589,36 @@ def test_cnn_side_stream_ordering_across_calls(dq):
         c.close()
     for x, y in zip(res[True], res[False]):
         assert np.array_equal(x, y)
+
+
+def test_cnn_comm_world1(dq):
+    """dqn_cnn_comm_init / the data-parallel flow of dqn_cnn_update at world 1 -- what is true there: the communicator exists
+    (ncclCommCount = 1), the update takes the data-parallel route (backward without the early fc-leaf step, all-reduce calls,
+    optimizer with grad_scale = 1 / 1) and leaves exactly the parameters and loss of the single-learner route; the stand-alone
+    dqn_cnn_allreduce_grads is the identity on the gradient buffer. Nothing is claimed about world > 1 (no multi-GPU box)."""
+    B = 8
+    rng = np.random.default_rng(81)
+    P, Pt = make_params(81), make_params(82)
+    s = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8); s2 = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+    a = rng.integers(0, A, B).astype(np.int32); r = rng.standard_normal(B).astype(np.float32); d = (rng.random(B) < 0.3).astype(np.float32)
+    isw = rng.uniform(0.3, 1.0, B).astype(np.float32)
+    out = {}
+    for dp in (False, True):
+        e = dq.CnnEngine(num_actions=A, max_batch=B, precision="f32")
+        e.set_params(P); e.set_params(Pt, target=True); e.set_optimizer(lr=1e-3)
+        if dp:
+            e.comm_init_native()
+            assert e.comm_ranks() == 1
+        else:
+            assert e.comm_ranks() == 0
+        losses = [e.update(s, a, r, s2, d, isw, 0.99, want_loss=True) for _ in range(2)]
+        out[dp] = (host(e.get_buffer("params")).copy(), losses)
+        if dp:
+            q = host(e.forward(s))
+            tg = (q + 0.5).astype(np.float32)
+            e.grads(s, tg, isw)
+            g0 = host(e.get_buffer("grad")).copy()
+            e.allreduce_grads()
+            assert np.array_equal(host(e.get_buffer("grad")), g0)
+        e.close()
+    assert out[True][1] == out[False][1] and np.array_equal(out[True][0], out[False][0])

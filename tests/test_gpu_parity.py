@@ -387,7 +387,7 @@ def test_act_parity(dq):
 
 # ------------------------------------------------------------------ the fused update
 @pytest.mark.parametrize("name,B,per", [("cfg1", 64, False), ("cfg1", 64, True), ("cfg2", 1024, True), ("cfg3", 2048, True),
-                                        ("cfg2", -1000, True), ("cfg2", -1024, False), ("cfg2", 16400, True)])   # B < 0 / 16 400 rows: dqn_net_big.hip
+                                        ("cfg2", -1000, True), ("cfg2", -1024, False)])   # B < 0: dqn_net_big.hip forced at |B| rows (16 400 rows: the direct test below)
 def test_fused_update_tracks_oracle(dq, name, B, per):
     """Agent._step (q_agent.py:146-169) as dqn_update_fused, 4 consecutive updates (graph replays) with a
     target sync in between, against the C oracle's whole-update driver on the same replay contents.
@@ -399,7 +399,7 @@ def test_fused_update_tracks_oracle(dq, name, B, per):
     N = 1 << L_
     big = B < 0                              # the 64-row kernels forced at |B| rows (DQN_FLAG_BIG_ROWS)
     B = abs(B)
-    lr = 1e-3 if B < 8192 else 2e-4          # (16 400-row sums: two f32 summation orders differ by ~1e-5 * lr / 1e-3 after the optimizer; the reference's lr)
+    lr = 1e-3
     e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=77, lr=lr, flags=dq._lib.FLAG_BIG_ROWS if big else 0)
     cr = oc.CReplay(N, D); ct = oc.CPer(L_) if per else None
     s, a, r, s2, d = make_batch(dims, 3000, 70, terminal_frac=0.1)
@@ -471,6 +471,58 @@ def test_gamma_injection_rebuilds_graphs(dq):
         e2.stream.synchronize()
     assert np.max(np.abs(e2.get_params(host=True) - e.get_params(host=True))) > 1e-6
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("per", [True, False])
+def test_big_update_one_step_direct(dq, per):
+    """VERDICT r02 #8b: the large-batch update (16 400 rows: k_per_sample2 / uniform -> k_big_rows -> k_big_dw -> k_big_reduce with
+    AdamW) checked DIRECTLY after ONE step instead of through a relaxed trajectory: on the rows the update itself drew
+    (DQN_BUF_BATCH_IDX, the IS weights it normalised) the gradient buffer is within 1e-5 of every leaf's scale of the f64
+    gradient of compute_loss at the f64 targets; the first moments are exactly (1 - b1) * g and (1 - b2) * g * g of that
+    buffer in f32; and the parameters are bit-for-bit the restatement's AdamW step (orc_adam_step) on it."""
+    import torch
+    dims = CFGS["cfg2"]
+    D, A = dims[0], dims[3]
+    B, L_ = 16400, 15
+    N = 1 << L_
+    lr = 1e-3
+    e = mk(dq, dims, capacity=N, use_per=per, max_batch=B, seed=5, lr=lr)
+    s, a, r, s2, d = make_batch(dims, N, 170, terminal_frac=0.1)
+    r = np.clip(r, -2, 2)
+    for k in range(0, N, 4096):
+        e.replay_add(s[k:k + 4096], a[k:k + 4096], r[k:k + 4096], s2[k:k + 4096], d[k:k + 4096] > 0)
+    if per:
+        pr = (np.random.default_rng(171).random(N).astype(np.float32) + np.float32(0.05))
+        for k in range(0, N, 4096):
+            e.per_set(np.arange(k, k + 4096, dtype=np.int32), pr[k:k + 4096])
+    P0, Pt = rand_params(dims, 172), rand_params(dims, 173)
+    e.set_params(P0); e.set_params(Pt, dq._lib.BUF_TARGET)
+    with torch.cuda.stream(e.stream):
+        e.update(B); e.stream.synchronize()
+    L = dq._lib
+    idx = host(e.buffer(L.BUF_BATCH_IDX, torch.int32))[:B].astype(np.int64)
+    isw = host(e.buffer(L.BUF_BATCH_ISW))[:B].copy() if per else None
+    if per:
+        assert np.all(np.diff(idx) >= 0) and 0 < isw.min() and isw.max() == 1.0
+    bs, ba, br, bs2, bd = s[idx], a[idx], r[idx], s2[idx], d[idx]
+    targets = onp.q_targets(P0, Pt, bs, ba, br, bs2, bd, 0.99, dims, np.float64)
+    g64, L64, _ = onp.grads(P0, bs, targets, dims, isw, np.float64)
+    g = host(e.buffer(L.BUF_GRAD)).copy()
+    assert abs(float(e.last_loss().item()) - L64) <= 1e-5 * max(1.0, abs(L64))
+    from deep_q_learning_amd._tree import shapes
+    o = 0
+    for mod, leaf, shp in shapes(dims):
+        n = int(np.prod(shp))
+        sc = np.abs(g64[o:o + n]).max()
+        assert np.max(np.abs(g[o:o + n] - g64[o:o + n])) <= 1e-5 * sc, (mod, leaf, np.max(np.abs(g[o:o + n] - g64[o:o + n])) / sc)
+        o += n
+    mu, nu = host(e.buffer(L.BUF_MU)), host(e.buffer(L.BUF_NU))
+    assert np.array_equal(mu, (np.float32(1.0) - np.float32(0.9)) * g)
+    assert np.array_equal(nu, (np.float32(1.0) - np.float32(0.999)) * (g * g))
+    Pc, _, _, cnt, _, _ = oc.adam_step(oc.Opt(lr, 0.9, 0.999, 1e-8, 1e-4, 1), P0.copy(), g, np.zeros_like(g), np.zeros_like(g), 0, 1.0, 1.0)
+    assert cnt == 1 and np.array_equal(e.get_params(host=True), Pc)
+    assert e.opt_count() == 1 and e.device_errors() == 0
+    e.close()
 
 
 # ----------------------------------------------------------------- synthetic actor

@@ -247,6 +247,65 @@ def test_data_parallel_recipe_gloo_world2():
     assert np.allclose(res[0][1], Pw, rtol=0, atol=1e-12)
 
 
+def _cnn_dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    from deep_q_learning_amd import dist as dd
+    r, w, _ = dd.init_from_env("gloo")
+    A, B = 6, 3
+    P = torch.tensor(onp.cnn_init_params(A, 0 if r == 0 else 99))
+    dd.broadcast_params(P)
+    P = P.numpy().copy()
+    rng = np.random.default_rng(500 + r)                          # own minibatch per rank
+    frames = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+    qv, _ = oc.cnn_forward(P, frames, A)
+    targets = (qv + rng.standard_normal((B, A)) * 0.7).astype(np.float32)
+    g, _ = oc.cnn_grads(P, frames, targets, None, A)
+    # the message plan of dqn_cnn_update with a communicator (csrc/dqn_cnn.hip): the fc weight leaf first (beside the backward),
+    # then the range below it and the range above it -- three in-place SUM all-reduces that together cover the buffer once
+    lo = 8 * 8 * 4 * 32 + 32 + 4 * 4 * 32 * 64 + 64 + 3 * 3 * 64 * 64 + 64
+    hi = lo + 3136 * 512
+    gt = torch.tensor(g)
+    for seg in (gt[lo:hi], gt[:lo], gt[hi:]):
+        dd.allreduce_grads(seg)
+    Pn, _, _, cnt, _, _ = oc.adam_step(oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), P, gt.numpy(), np.zeros_like(P), np.zeros_like(P), 0, 1.0, 1.0, grad_scale=1.0 / w)
+    q.put((r, Pn, gt.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cnn_data_parallel_recipe_gloo_world2():
+    """SURVEY 8(e) for the CNN (BASELINE configs[4] in its multi-GPU form): two learners with their own minibatches, the
+    gradient summed in the three messages dqn_cnn_update issues with a communicator (fc leaf; below it; above it), AdamW with
+    grad_scale = 1 / world -- the replicas stay bit-identical and equal ONE learner stepping on the sum of the two gradients.
+    (CPU ranks on gloo with the restatement's gradients; on hardware the same plan runs on RCCL: unmeasured, no multi-GPU box.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_cnn_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    A, B = 6, 3
+    P = onp.cnn_init_params(A, 0)
+    gs = []
+    for r in range(2):
+        rng = np.random.default_rng(500 + r)
+        frames = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+        qv, _ = oc.cnn_forward(P, frames, A)
+        targets = (qv + rng.standard_normal((B, A)) * 0.7).astype(np.float32)
+        gs.append(oc.cnn_grads(P, frames, targets, None, A)[0])
+    assert np.array_equal(res[0][2], gs[0] + gs[1])               # every element summed exactly once
+    Pn, _, _, _, _, _ = oc.adam_step(oc.Opt(1e-3, 0.9, 0.999, 1e-8, 1e-4, 1), P, gs[0] + gs[1], np.zeros_like(P), np.zeros_like(P), 0, 1.0, 1.0, grad_scale=0.5)
+    assert np.array_equal(res[0][1], Pn)
+
+
 def test_cnn_oracle_reproduces_golden():
     """the Nature-CNN restatement (forward f32 / f64, loss gradient f32 / f64) against the committed vector
     tests/golden/cnn_B4_seed7.npz (regression pin; inputs re-generated from the recorded seeds and checked by their sums)"""
