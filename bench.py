@@ -535,7 +535,7 @@ def cnn_lines(dq):
                          "unit": "TFLOP/s", "frac": fl * Bc / us / 1e6 / peak, "traffic": None, "note": note}
         e.close()
     # the loop around it: 512 synthetic frame-stack envs, 4 vector env steps (act, add to the frame ring and the PER index) per
-    # update of 512 PER-sampled transitions (General/QLearning/cnn_agent.py); the synthetic env (torch.randint frames) is inside
+    # update of 512 PER-sampled transitions (General/QLearning/cnn_agent.py); the synthetic env (Philox frames, on the device) is inside
     from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
     ag = CnnVectorAgent(n_envs=Bc, num_actions=A_, capacity=1 << 14, batch_size=Bc, precision="bf16", train_frequency=4, seed=5, n_step=3)
     ag.init_params(torch.randn(ag.cnn.param_count) * 0.02)
@@ -552,7 +552,8 @@ def cnn_lines(dq):
                                       "updates_per_sec": 1e6 / us, "env_steps_per_sec": 4 * Bc * 1e6 / us, "device_errors": ag.index.device_errors(),
                                       "note": "BASELINE configs[4] shape on ONE GPU, n-step 3 PER: 4 vector env steps of 512 synthetic frame-stack envs (CNN act + "
                                               "frame-ring add + PER index add) + 1 update from the ring (PER sample, gather, 3 forwards, backward, AdamW, priority write-back); "
-                                              "host-driven loop (no graph), synthetic env = torch.randint"}
+                                              "host-driven loop (no graph); r03: the synthetic env lives on the device (dqn_cnn_env_step_synth: forward 5 launches + 1 "
+                                              "policy / transition / ring kernel per vector step, + 1 index launch), ~60 launches per iteration"}
     ag.close()
     return out
 

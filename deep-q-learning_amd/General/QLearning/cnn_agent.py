@@ -2,17 +2,19 @@
 envs that emit stacks of four 84x84 u8 frames, the Nature-CNN dueling Q-net, prioritized replay. Host logic only -- every
 numerical step is a C-ABI call:
 
-  act              dqn_cnn_act            (CNN forward + epsilon-greedy, q_agent.py:137-141)
-  add              dqn_cnn_replay_add     (frame ring, replay_buffer.py:58-65)  +  dqn_replay_add on the index engine, whose
-                                          sum tree gives the new rows the running maximum priority
-  sample           dqn_per_sample         on the index engine (a dqn_handle of the same capacity: positions only)
+  act + env + add  dqn_cnn_env_step_synth (r03: ONE call per vector step -- CNN forward + epsilon-greedy (q_agent.py:137-141), the
+                                          synthetic transition drawn on the device, ReplayBuffer.add into the frame ring
+                                          (replay_buffer.py:58-65); the envs' current frames are the ring's own s' rows)
+                   dqn_per_index_advance  on the index engine: the new positions enter its sum tree at the running maximum
+                                          priority; the index holds POSITIONS only (r02 fed it rows of zeros)
+  sample           dqn_per_sample         on the index engine (a dqn_handle of the same capacity)
   n-step           rows are 1-step; dqn_cnn_update_replay(n_step, n_envs) assembles the n-step transition that starts at a sampled
                    row from its n - 1 successors; the index is told of a step n - 1 steps late
   update           dqn_cnn_update_replay  (gather, three forwards, TD rule, backward, AdamW; q_agent.py:146-169)
   write-back       dqn_per_update_sorted  with |delta|
 
-The env is synthetic (there is no ALE here and no network): frames are uniform u8, rewards N(0,1), dones Bernoulli(p_done) --
-the shape of PongNoFrameskip-v4 after the usual wrappers, not its dynamics.
+The env is synthetic (there is no ALE here and no network): frames are uniform u8 (Philox, drawn by the step kernel), rewards
+Irwin-Hall normals, dones Bernoulli(p_done) -- the shape of PongNoFrameskip-v4 after the usual wrappers, not its dynamics.
 """
 from __future__ import annotations
 
@@ -36,14 +38,11 @@ class CnnVectorAgent:
         self.cnn = CnnEngine(num_actions=num_actions, max_batch=max(n_envs, batch_size), precision=precision, device=device)
         self.cnn.replay_init(capacity)
         self.cnn.set_optimizer(lr=lr)
-        # the PER tree: a dqn_handle whose ring holds one dummy float per position
-        self.index = Engine(EngineConfig(obs_dim=8, hidden1=16, hidden2=16, num_actions=4, capacity=capacity, use_per=True,
+        # the PER tree: a dqn_handle used as a positions-only index (dqn_per_index_advance; its own ring is one float per position)
+        self.index = Engine(EngineConfig(obs_dim=1, hidden1=16, hidden2=16, num_actions=2, capacity=capacity, use_per=True,
                                          max_batch=max(n_envs, batch_size), seed=seed), device=device)
         dev = self.cnn.device
-        self.gen = torch.Generator(device=dev); self.gen.manual_seed(seed + 1)
-        self.frames = self._new_frames()
-        self._zeros = (torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.int32, device=dev),
-                       torch.zeros((n_envs,), device=dev), torch.zeros((n_envs, 8), device=dev), torch.zeros((n_envs,), dtype=torch.uint8, device=dev))
+        self.cnn.env_reset_synth(n_envs, seed)
         self.td_abs = torch.empty((self.B,), dtype=torch.float32, device=dev)
         self._pos = torch.arange(n_envs, dtype=torch.int32, device=dev); self._zero_prio = torch.zeros((n_envs,), dtype=torch.float32, device=dev)
         self.env_steps = self.updates = 0
@@ -55,20 +54,13 @@ class CnnVectorAgent:
     def init_params(self, flat, target_flat=None):
         self.cnn.set_params(flat); self.cnn.set_params(flat if target_flat is None else target_flat, target=True)
 
-    def _new_frames(self):
-        return torch.randint(0, 256, (self.n_envs, 84, 84, 4), dtype=torch.uint8, device=self.cnn.device, generator=self.gen)
-
     def env_step(self):
-        """one vector env step: act, synthetic transition, both rings"""
-        n, dev = self.n_envs, self.cnn.device
-        a = self.cnn.act(self.frames, self.epsilon, self.seed, self.env_steps)
-        nxt = self._new_frames()
-        r = torch.randn((n,), device=dev, generator=self.gen)
-        d = (torch.rand((n,), device=dev, generator=self.gen) < self.p_done).float()
-        first = self.cnn.replay_add(self.frames, a, r, nxt, d)
+        """one vector env step: act + synthetic transition + frame ring (one C-ABI call), then the index"""
+        n = self.n_envs
+        first = self.cnn.env_step_synth(self.epsilon, self.p_done)
         assert first == (self.env_steps * n) % self.cnn.capacity, (first, self.env_steps)      # the two rings move in lockstep
         if self.n_step == 1:
-            self.index.replay_add(*self._zeros)
+            self.index.per_index_advance(n)
         else:
             # the frame ring holds one row per env step; the n-step transition that starts at a row exists once its n - 1
             # successors do. So the PER index learns of step t - n + 1 when step t arrives (its own ring counter is n - 1 steps
@@ -76,8 +68,7 @@ class CnnVectorAgent:
             if self.env_steps * n >= self.cnn.capacity:
                 self.index.per_set_sorted(self._pos + first, self._zero_prio)
             if self.env_steps >= self.n_step - 1:
-                self.index.replay_add(*self._zeros)
-        self.frames = nxt
+                self.index.per_index_advance(n)
         self.env_steps += 1
         self.epsilon = max(self.epsilon * self.decay, self.min_eps)
 

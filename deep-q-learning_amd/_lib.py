@@ -86,6 +86,9 @@ SIGNATURES = {
     "dqn_cnn_create": [_I32, _I32, _I32, C.POINTER(_P)],
     "dqn_cnn_destroy": [_P],
     "dqn_cnn_set_flags": [_P, _I32],
+    "dqn_cnn_env_reset_synth": [_P, _I32, C.c_uint64, _P],
+    "dqn_cnn_env_step_synth": [_P, C.c_float, C.c_float, C.POINTER(_I64), _P],
+    "dqn_per_index_advance": [_P, _I32, _P],
     "dqn_cnn_comm_init": [_P, _P, _I32, _I32],
     "dqn_cnn_comm_count_host": [_P, C.POINTER(_I32)],
     "dqn_cnn_allreduce_grads": [_P, _I32, _P],

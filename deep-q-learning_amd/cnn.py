@@ -163,6 +163,16 @@ class CnnEngine:
         L.check(self.lib.dqn_cnn_act(self.h, _ptr(x), x.shape[0], float(epsilon), int(seed), int(ctr), _ptr(a), self._s()))
         return a
 
+    def env_reset_synth(self, n_envs, seed=0):
+        """reset() of n synthetic frame-stack envs that live on the device (dqn_cnn_env_reset_synth; needs replay_init first)"""
+        L.check(self.lib.dqn_cnn_env_reset_synth(self.h, int(n_envs), int(seed), self._s()))
+
+    def env_step_synth(self, epsilon, p_done=0.01):
+        """one vector env step on the device: CNN act + synthetic transition + ring add; returns the ring row of env 0"""
+        first = C.c_int64(0)
+        L.check(self.lib.dqn_cnn_env_step_synth(self.h, float(epsilon), float(p_done), C.byref(first), self._s()))
+        return first.value
+
     def replay_init(self, capacity):
         """ReplayBuffer.__init__ (replay_buffer.py:20-34) for frame stacks"""
         L.check(self.lib.dqn_cnn_replay_init(self.h, int(capacity)))

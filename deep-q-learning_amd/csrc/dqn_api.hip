@@ -377,6 +377,18 @@ extern "C" int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, c
     return DQN_OK;
 }
 
+/* The handle as a POSITIONS-ONLY prioritized index (the CNN loop keeps its transitions in the frame ring of a dqn_cnn_handle): n new
+ * positions enter at the running max priority exactly as dqn_replay_add's would -- counter, size, leaves -- without any row data. */
+extern "C" int dqn_per_index_advance(dqn_handle *h, int32_t n, void *stream) {
+    REQUIRE(h, "null argument");
+    if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
+    REQUIRE(n >= 1 && n <= h->cfg.capacity, "dqn_per_index_advance: n=%d must be in [1, capacity]", n);
+    hipStream_t st = (hipStream_t)stream;
+    launch_per_add(st, h->st, h->tree, h->Ntree, h->L, n, h->cfg.capacity, 1);      // (one launch: counter, size and leaves)
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
 extern "C" int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter) {
     REQUIRE(h, "null argument");
     DqnState s;

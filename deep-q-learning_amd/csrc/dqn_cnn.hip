@@ -942,6 +942,7 @@ struct dqn_cnn_handle {
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
     int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
+    int env_n = 0; uint64_t env_seed = 0; long long env_steps = 0; const uint8_t *env_cur = nullptr;   // dqn_cnn_env_*_synth
     void *comm = nullptr; int rank = 0, world = 1;     // dqn_cnn_comm_init: per-GPU learners, one gradient all-reduce per update
     hipEvent_t ev_fc = nullptr;                        // the fc leaf's all-reduce on the side stream (data-parallel update)
 };
@@ -1438,6 +1439,74 @@ extern "C" int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int
     CNN_TRY(put(h->ring_a, a, 4)); CNN_TRY(put(h->ring_r, r, 4)); CNN_TRY(put(h->ring_d, d, 4));
     if (first_index) *first_index = pos;
     h->ring_counter += n;
+    return DQN_OK;
+}
+
+// ---- the synthetic vector env of BASELINE configs[4]'s shape ON THE DEVICE (no physics; frames are uniform u8,
+// rewards Irwin-Hall normals, dones Bernoulli(p_done)): one kernel files a whole vector step in the frame ring --
+//   ring_s[row]  = the env's current frame stack (copied from where the previous step left it: the ring's own s' row),
+//   ring_s2[row] = the next frame stack, drawn here: 16 bytes per Philox4x32-10 call, counter (step, 16-byte piece index),
+//   ring_r / ring_d from one more draw per env; ring_a was written by the policy kernel in front of it.
+// The next step's "current frames" ARE the s' rows just written (no copy back to a staging buffer).
+__global__ void __launch_bounds__(256)
+k_cnn_synth_step(const uint8_t *__restrict__ cur, uint8_t *__restrict__ ring_s, uint8_t *__restrict__ ring_s2, float *__restrict__ ring_r,
+                 float *__restrict__ ring_d, long long pos, int n, unsigned long long seed, unsigned long long step, float p_done,
+                 const float *__restrict__ q, int A, float epsilon, int32_t *__restrict__ ring_a) {
+    const long long pieces = (long long)n * (CNN_FRAME_BYTES / 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(cur);
+    uint4 *ds = reinterpret_cast<uint4 *>(ring_s + pos * CNN_FRAME_BYTES), *d2 = reinterpret_cast<uint4 *>(ring_s2 + pos * CNN_FRAME_BYTES);
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pieces; p += (long long)gridDim.x * blockDim.x) {
+        const uint4 v = src[p];
+        const u32x4 o = philox_draw(seed, step, (uint32_t)p, DQN_STREAM_ENV);
+        ds[p] = v;
+        d2[p] = uint4{o.x, o.y, o.z, o.w};
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const u32x4 o = philox_draw(seed, step, 0x80000000u + (uint32_t)i, DQN_STREAM_ENV);        // (piece indices stay below 2^31)
+        const u32x4 o2 = philox_draw(seed, step, 0xC0000000u + (uint32_t)i, DQN_STREAM_ENV);
+        ring_r[pos + i] = (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;     // Irwin-Hall normal (as ih_normal)
+        ring_d[pos + i] = u01(o2.x) < p_done ? 1.0f : 0.0f;
+        ring_a[pos + i] = policy_row(q + (long long)i * A, A, epsilon, seed, step, i);             // q_agent.py:137-141, as dqn_cnn_act
+    }
+}
+__global__ void __launch_bounds__(256)
+k_cnn_synth_frames(uint8_t *__restrict__ dst, int n, unsigned long long seed, unsigned long long step) {
+    const long long pieces = (long long)n * (CNN_FRAME_BYTES / 16);
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pieces; p += (long long)gridDim.x * blockDim.x) {
+        const u32x4 o = philox_draw(seed, step, (uint32_t)p, DQN_STREAM_ENV);
+        reinterpret_cast<uint4 *>(dst)[p] = uint4{o.x, o.y, o.z, o.w};
+    }
+}
+
+/* reset() of n synthetic frame-stack envs: the first observations are the Philox frames of "step" 2^63 + seed-independent constant;
+ * needs the ring (dqn_cnn_replay_init) with capacity % n == 0 so that a vector step never wraps inside the ring */
+extern "C" int dqn_cnn_env_reset_synth(dqn_cnn_handle *h, int32_t n, uint64_t seed, void *stream) {
+    CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
+    CNN_REQ(n >= 1 && n <= h->max_batch && h->ring_cap % n == 0, "dqn_cnn_env_reset_synth: n must divide the ring capacity and fit max_batch");
+    h->env_n = n; h->env_seed = seed; h->env_steps = 0;
+    h->env_cur = h->stage_s2;                                           // (free until the first update stages a batch: by then the envs live in the ring)
+    hipLaunchKernelGGL(k_cnn_synth_frames, dim3(1024), dim3(256), 0, (hipStream_t)stream, h->stage_s2, n, seed, 0x8000000000000000ull);
+    CNN_TRY(hipGetLastError());
+    CNN_TRY(hipStreamSynchronize((hipStream_t)stream));                 // (the staging buffer must not be reused before the first step has read it)
+    return DQN_OK;
+}
+
+/* One vector env step, everything on the device (q_agent.py:176-183 for n envs): epsilon-greedy actions of the CNN on the current
+ * frame stacks (Philox policy stream (seed, step, env), as dqn_cnn_act), the synthetic transition, ReplayBuffer.add of the n
+ * transitions at ring rows [first, first + n). first_index (optional): the row of env 0. */
+extern "C" int dqn_cnn_env_step_synth(dqn_cnn_handle *h, float epsilon, float p_done, int64_t *first_index, void *stream) {
+    CNN_REQ(h && h->ring_arena && h->env_n > 0, "no envs: call dqn_cnn_env_reset_synth");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = h->env_n;
+    const long long pos = h->ring_counter % h->ring_cap;
+    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, h->env_cur, n, h->q[0], stream); if (rc) return rc;
+    hipLaunchKernelGGL(k_cnn_synth_step, dim3(2048), dim3(256), 0, st, h->env_cur, h->ring_s, h->ring_s2, h->ring_r, h->ring_d, pos, n,
+                       h->env_seed, (unsigned long long)h->env_steps, p_done, h->q[0], h->A, epsilon, h->ring_a);
+    CNN_TRY(hipGetLastError());
+    h->env_cur = h->ring_s2 + pos * CNN_FRAME_BYTES;
+    if (first_index) *first_index = pos;
+    h->ring_counter += n; h->env_steps += 1;
     return DQN_OK;
 }
 

@@ -787,13 +787,23 @@ k_per_top_seg(DqnState *st, float *tree, int L, const float *__restrict__ pmax_p
 // ------------------------------------------------- leaf-range insert (ring add with PER)
 // device code: per_add_range_wg / per_add_slow in dqn_per_device.h
 __global__ void __launch_bounds__(1024)
-k_per_add(const DqnState *st, float *tree, long long Nt, int L, int n, long long cap) {
+k_per_add(DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const unsigned long long c_base = st->ring_counter - (unsigned long long)n;   // slots just written
+    // advance = 0: the n slots have just been written (ring_counter is past them); 1 (dqn_per_index_advance): this launch IS the
+    // add -- the slots start at ring_counter, committed by thread 0 once every thread has read it
+    const unsigned long long c_base = advance ? st->ring_counter : st->ring_counter - (unsigned long long)n;
     const long long a = (long long)(c_base % (unsigned long long)cap);
     const float pmax = st->pmax;
     if (n <= RANGE_MAX && a + n <= cap) per_add_range_wg(tree, Nt, L, a, n, pmax, lds);
     else per_add_slow(tree, Nt, L, c_base, n, pmax, cap);
+    if (advance) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long c1 = c_base + (unsigned long long)n;                  // replay_buffer.py:64-65
+            st->ring_counter = c1;
+            st->size = (long long)(c1 < (unsigned long long)cap ? c1 : (unsigned long long)cap);
+        }
+    }
 }
 
 
@@ -873,9 +883,9 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 
 static inline int pow2_threads(int n, int lo, int hi) { int t = lo; while (t < n && t < hi) t <<= 1; return t; }
 
-void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap) {
+void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance) {
     const size_t lds = sizeof(float) * 64;
-    hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, st, tree, Nt, L, n, cap);
+    hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, const_cast<DqnState *>(st), tree, Nt, L, n, cap, advance);
 }
 
 

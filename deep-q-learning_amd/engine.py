@@ -197,6 +197,10 @@ class Engine:
         d = d.to(torch.uint8).view(n)
         L.check(self.lib.dqn_replay_add(self.h, _ptr(s), _ptr(a), _ptr(r), _ptr(s2), _ptr(d), n, self._s()))
 
+    def per_index_advance(self, n):
+        """the handle as a positions-only prioritized index: n new positions at the running max priority (no row data)"""
+        L.check(self.lib.dqn_per_index_advance(self.h, int(n), self._s()))
+
     def replay_size(self):
         size, ctr = C.c_int64(), C.c_int64()
         L.check(self.lib.dqn_replay_size_host(self.h, C.byref(size), C.byref(ctr)))

@@ -119,6 +119,8 @@ int dqn_set_gamma(dqn_handle *h, float gamma);
  * counter % capacity. With use_per the new leaves get the running max priority. */
 int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, const float *r,
                    const float *s2, const uint8_t *d, int32_t n, void *stream);
+/* the handle as a positions-only prioritized index: n new positions at the running max priority (counter, size, leaves), no row data */
+int dqn_per_index_advance(dqn_handle *h, int32_t n, void *stream);
 int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter);   /* synchronises */
 
 /* sample_batch (replay_buffer.py:68-85). idx_in != NULL: gather exactly those rows
@@ -305,6 +307,10 @@ int dqn_cnn_act(dqn_cnn_handle *h, const uint8_t *frames, int32_t n, float epsil
 int dqn_cnn_replay_init(dqn_cnn_handle *h, int64_t capacity);
 int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2,
                        const float *d, int32_t n, int64_t *first_index, void *stream);
+/* The synthetic frame-stack vector env of BASELINE configs[4]'s shape on the device (no ALE here): reset n envs, then
+ * one call per vector step = CNN act + synthetic transition (Philox frames / rewards / dones) + ReplayBuffer.add of the n rows. */
+int dqn_cnn_env_reset_synth(dqn_cnn_handle *h, int32_t n, uint64_t seed, void *stream);
+int dqn_cnn_env_step_synth(dqn_cnn_handle *h, float epsilon, float p_done, int64_t *first_index, void *stream);
 int dqn_cnn_replay_size_host(const dqn_cnn_handle *h, int64_t *size, int64_t *counter);
 /* n_step = 1: the stored rows. n_step 2..8 with the rows stored step-major (n_envs rows per env step, capacity a multiple of
  * n_envs): the n-step transition that STARTS at each row -- s and a of the row, R = r_0 + gamma (r_1 + ...) cut after the first done,

@@ -622,3 +622,34 @@ def test_cnn_comm_world1(dq):
             assert np.array_equal(host(e.get_buffer("grad")), g0)
         e.close()
     assert out[True][1] == out[False][1] and np.array_equal(out[True][0], out[False][0])
+
+
+def test_cnn_env_step_synth(dq):
+    """r03 dqn_cnn_env_step_synth: the synthetic frame-stack vector env on the device (act + transition + ring add in one call).
+    Against a numpy model: every next-frame byte is the Philox4x32-10 draw (seed, step, 16-byte piece index, env stream) of the
+    restatement's generator; s of a step's rows == s' of the previous step's rows (the envs live in the ring's own s' rows);
+    at epsilon = 0 the stored actions are the arg-max of the CNN on those frames; rewards / dones in range; counters."""
+    import torch
+    n, cap, seed = 8, 64, 11
+    e = dq.CnnEngine(num_actions=A, max_batch=16, precision="f32")
+    e.set_params(make_params(91)); e.replay_init(cap)
+    e.env_reset_synth(n, seed)
+    firsts = [e.env_step_synth(0.0, 0.3) for _ in range(10)]              # 80 rows into 64: wraps
+    assert firsts == [(t * n) % cap for t in range(10)] and e.replay_size() == (cap, 10 * n)
+    pieces = n * (84 * 84 * 4 // 16)
+    for t in (9, 8, 3):                                                   # rows still in the ring (steps 2 .. 9)
+        idx = ((t * n) % cap + np.arange(n)).astype(np.int32)
+        s, a, r, s2, d = (host(x) for x in e.replay_gather(idx))
+        want = onp.philox_draw(seed, t, pieces, onp.STREAM_ENV).astype("<u4").view(np.uint8).reshape(n, 84, 84, 4)
+        assert np.array_equal(s2, want), t
+        prev = ((t - 1) * n) % cap + np.arange(n)
+        if t - 1 >= 2:
+            assert np.array_equal(s, host(e.replay_gather(prev.astype(np.int32))[3])), t     # s(t) = s'(t - 1)
+        q = host(e.forward(torch.as_tensor(s)))
+        top2 = np.sort(q, axis=1)
+        clear = top2[:, -1] - top2[:, -2] > 1e-6
+        assert np.array_equal(a[clear], q.argmax(1)[clear])
+        assert np.isfinite(r).all() and np.abs(r).max() < 3.5 and set(np.unique(d)) <= {0.0, 1.0}
+    allr = host(e.replay_gather(np.arange(cap, dtype=np.int32))[2]); alld = host(e.replay_gather(np.arange(cap, dtype=np.int32))[4])
+    assert 0.05 < alld.mean() < 0.6 and allr.std() > 0.5
+    e.close()
