@@ -120,7 +120,8 @@ static void L_pack(dqn_handle *h, hipStream_t s, const float *params, float *pac
         if (pack == h->pack) { launch_pack(s, h->m, params, h->pack_act); launch_pack_w2k16(s, h->m, params, h->pack_act); }   // the actor kernel reads f32 shadows of the online net
     } else launch_pack(s, h->m, params, pack);
 }
-static bool use_big(dqn_handle *h, int B) { return h->big_slab != nullptr && big_supported(h->m, B, h->big_any); }
+static bool big_from(const dqn_handle *h, int B) { return h->big_any || (h->bf16 && B >= DQN_BIG_MIN_BF16); }
+static bool use_big(dqn_handle *h, int B) { return h->big_slab != nullptr && big_supported(h->m, B, big_from(h, B)); }
 static void L_fwd(dqn_handle *h, hipStream_t s, const FwdPass *p, int n, int B, const SampleArgs *smp = nullptr,
                   const BwdArgs *fuse = nullptr) {
     if (use_big(h, B) && !smp && !fuse) {                          // large batches: 64-row tiles (dqn_net_big.hip), forward only
@@ -225,7 +226,7 @@ extern "C" int dqn_create(const dqn_config *cfg, dqn_handle **out) {
     add(&h->ph1, Bp * H1 * esz); add(&h->ph2, Bp * H2 * esz);
     add(&h->pdz1, Bp * H1 * esz); add(&h->pdz2, Bp * H2 * esz); add(&h->pdz3, Bp * 16 * esz);
     add(&h->loss_part, (Bp / 16) * 4); add(&h->loss_dev, 4, DQN_BUF_LOSS); add(&h->scratch, Bp * 4);
-    if (big_supported(h->m, cfg->max_batch, h->big_any)) {
+    if (big_supported(h->m, cfg->max_batch, big_from(h, cfg->max_batch))) {
         add(&h->big_slab, big_slab_floats(cfg->max_batch, h->num_cus) * 4); add(&h->big_colsum, big_colsum_floats(cfg->max_batch) * 4);
     }
     h->tile_stride = (int)(Bp / 16) + 2;

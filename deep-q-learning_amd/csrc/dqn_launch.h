@@ -114,6 +114,7 @@ void launch_u8_to_f32(hipStream_t s, const uint8_t *in, float *out, int n);
 
 // ----- large-batch f32 kernels (dqn_net_big.hip): 64 rows per workgroup on v_mfma_f32_32x32x2_f32 -------------
 #define DQN_BIG_MIN 16384           // batch rows from which the 64-row kernels replace the 16-row ones (measured crossover: tools/sweep.py)
+#define DQN_BIG_MIN_BF16 8192       // the same crossover in the bf16 mode (r03 sweep: update 96 vs 120 us at 8 192 rows, 96 vs 75 at 4 096)
 #define DQN_BIG_MAX_SLICES 64       // batch slices of the split-K weight-gradient GEMM (slab size)
 bool big_supported(const NetDims &m, int B, bool any_size = false);   // any_size: from 64 rows (DQN_FLAG_BIG_ROWS)
 size_t big_slab_floats(int max_batch, int num_cus);

@@ -39,14 +39,15 @@ if os.path.exists(f"gpurun_out/pmcs_{tag}.json"):          # the stand-alone sam
     pmc.update(json.load(open(f"gpurun_out/pmcs_{tag}.json")))
 json.dump(pmc, open(f"profiles/{rnd}_pmc.json", "w"), indent=1)
 mf = {}
-for part in ("bench", "big", "cnn", "cnnf32"):                               # MFMA / wave-state counter passes
+for part in ("bench", "big", "big16", "big16f", "bench16", "cnn", "cnnf32"):                               # MFMA / wave-state counter passes
     f2 = f"gpurun_out/pmcm_{tag}_{part}.json"
     if os.path.exists(f2):
         mf.update({k: v for k, v in json.load(open(f2)).items() if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0})
 if mf:
     json.dump(mf, open(f"profiles/{rnd}_pmc_mfma.json", "w"), indent=1)
 for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"), (f"gpurun_out/cnn_{tag}.txt", f"profiles/{rnd}_cnn_kernels.txt"), (f"gpurun_out/cnn_sweep_{tag}.json", f"profiles/{rnd}_cnn_sweep.json"),
-                 (f"gpurun_out/probe_{tag}.json", f"profiles/{rnd}_per_sample_probe.json")):
+                 (f"gpurun_out/probe_{tag}.json", f"profiles/{rnd}_per_sample_probe.json"), (f"gpurun_out/wprobe_{tag}.json", f"profiles/{rnd}_per_write_probe.json"),
+                 (f"gpurun_out/pmcw_{tag}.json", f"profiles/{rnd}_pmc_per_write.json")):
     if os.path.exists(src):
         shutil.copy(src, dst)
 for s in glob.glob(f"gpurun_out/sweep_{tag}*.json"):

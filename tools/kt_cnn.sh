@@ -17,7 +17,7 @@ f = sorted(glob.glob("$GRAFT_REPO_ROOT/gpurun_out/kt_$tag/*/*kernel_trace.csv"))
 acc = collections.defaultdict(list); order = []
 for r in csv.DictReader(open(f)):
     n = dem(r["Kernel_Name"])
-    if "k_cnn" in n or "k_td" in n:
+    if "k_cnn" in n or "k_td" in n or "k_conv" in n:
         n = re.sub(r"\(.*", "", n).replace("void ", "")[:60]
         if n not in acc: order.append(n)
         acc[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

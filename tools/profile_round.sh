@@ -10,12 +10,20 @@ bash $R/tools/prof_pmc.sh $tag 2>&1 | tail -8
 bash $R/tools/prof_pmc_sample.sh $tag 2>&1 | tail -7
 bash $R/tools/prof_pmc_mfma.sh ${tag}_bench $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2 2>&1 | grep "^k_\|rc=" | cut -c1-330
 bash $R/tools/prof_pmc_mfma.sh ${tag}_big $R/tools/big_probe.py --mode update --log2 17 --reps 6 2>&1 | grep "^k_big\|rc=" | cut -c1-330
+# r03: the bf16 MLP kernels -- the 64-row path (k_big_fwd16 / k_big_rows16_bwd / k_big_dw16 / k_big_reduce<true>) and the 16-row bench path
+# (k_qnet_fwd16, k_dw16, the bf16 k_actor)
+bash $R/tools/prof_pmc_mfma.sh ${tag}_big16 $R/tools/big_probe.py --mode update --log2 17 --reps 6 --precision bf16 2>&1 | grep "k_big\|rc=" | cut -c1-330
+bash $R/tools/prof_pmc_mfma.sh ${tag}_big16f $R/tools/big_probe.py --mode fwd --log2 17 --reps 6 --precision bf16 2>&1 | grep "k_big\|rc=" | cut -c1-330
+bash $R/tools/prof_pmc_mfma.sh ${tag}_bench16 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --profile-steps 2 --precision bf16 2>&1 | grep "^k_\|rc=" | cut -c1-330
+# r03: the sorted priority write-back by leaf segments: time per call over batch sizes, FETCH_SIZE / WRITE_SIZE per launch
+bash $R/tools/prof_pmc_write.sh $tag 2>&1 | tail -8
 bash $R/tools/prof_pmc_mfma.sh ${tag}_cnn $R/tools/cnn_probe.py --mode update --reps 6 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
 bash $R/tools/prof_pmc_mfma.sh ${tag}_cnnf32 $R/tools/cnn_probe.py --mode update --reps 6 --precision f32 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
 (bash $R/tools/kt_cnn.sh ${tag}_ub --mode update; bash $R/tools/kt_cnn.sh ${tag}_uf --mode update --precision f32; bash $R/tools/kt_cnn.sh ${tag}_fb --mode forward; bash $R/tools/kt_cnn.sh ${tag}_ff --mode forward --precision f32) > $out/cnn_$tag.txt 2>&1
 tail -3 $out/cnn_$tag.txt
 cd $R
 python tools/per_sample_probe.py --json $out/probe_$tag.json 2>&1 | tail -8
+python tools/per_write_probe.py --json $out/wprobe_$tag.json 2>&1 | tail -22
 python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
 python tools/sweep.py --max-log2 17 --no-actor --precision bf16 --json $out/sweep_${tag}_bf16.json 2>&1 | tail -2 | cut -c1-300
 python tools/cnn_sweep.py --json $out/cnn_sweep_$tag.json 2>&1 | tail -8 | cut -c1-260

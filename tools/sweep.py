@@ -38,11 +38,12 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--no-actor", action="store_true")
+    ap.add_argument("--big-any", action="store_true", help="force the 64-row large-batch kernels at every batch size (crossover search)")
     args = ap.parse_args()
     peak = 157.3 if args.precision == "f32" else 2500.0
     maxB = 1 << args.max_log2
     eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=H1, hidden2=H2, num_actions=A, capacity=1 << L, use_per=True,
-                                    max_batch=maxB, seed=3, precision=args.precision))
+                                    max_batch=maxB, seed=3, precision=args.precision, flags=dq._lib.FLAG_BIG_ROWS if args.big_any else 0))
     gen = torch.Generator(device=eng.device); gen.manual_seed(0)
     eng.set_params(torch.randn(eng.param_count) * 0.05); eng.sync_target()
     bench.prefill(eng, gen)
