@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DQN_ABI_VERSION 2
+#define DQN_ABI_VERSION 3
 
 typedef enum {
     DQN_OK = 0,

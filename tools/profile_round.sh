@@ -27,3 +27,8 @@ python tools/per_write_probe.py --json $out/wprobe_$tag.json 2>&1 | tail -22
 python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
 python tools/sweep.py --max-log2 17 --no-actor --precision bf16 --json $out/sweep_${tag}_bf16.json 2>&1 | tail -2 | cut -c1-300
 python tools/cnn_sweep.py --json $out/cnn_sweep_$tag.json 2>&1 | tail -8 | cut -c1-260
+# gpurun merges at most 64 MiB back: keep the summaries (json / txt / stats) and the one kernel trace collect_profiles.py reads, drop the raw counter dumps
+find $out -name "*counter_collection.csv" -delete 2>/dev/null
+find $out -name "*.db" -delete 2>/dev/null
+for d in $out/pmc_* $out/pmcs_* $out/pmcw_* $out/pmcm_* $out/kt_*; do [ -d "$d" ] && rm -rf "$d"; done
+du -sh $out | tail -1
