@@ -53,39 +53,39 @@ k_big_reduce(NetDims m, const float *__restrict__ slab, int KS, const float *__r
     AdamCoef co{};
     if (ad.P) co = adam_coef(st, ad.b1, ad.b2, &b1pow, &b2pow);
     if ((int)blockIdx.x < wblocks) {
-        const int i = blockIdx.x * 256 + threadIdx.x;
+        // FOUR lanes per weight element (r03): lane `part` sums a contiguous quarter of the element's partials -- (slice, half) order,
+        // all of its loads in flight together -- and the quarters are combined (p0 + p1) + (p2 + p3) by shuffles: a fixed order, so
+        // the result is deterministic. One thread per element walked its 32-64 partials in four dependent batches with ~270
+        // workgroups on the machine: 44 us for a 33 MB slab (0.7 TB/s, latency-bound) at B = 2^17.
+        const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, part = t & 3;
         // slab address of the element inside a slot, slot of the first partial, partials per slice (light tiles: two halves)
         long long off = -1; int nh = 1;
         if (i < (int)m.o_b1)      { const int k = i / m.H1, n = i - k * m.H1; off = 4ll * 128 * 128 + k * 256 + n; nh = 2; }
         else if (i >= (int)m.o_w2 && i < (int)m.o_b2) { const int u = i - (int)m.o_w2, k = u / m.H2, n = u - k * m.H2; off = (long long)(2 * (k >> 7) + (n >> 7)) * 128 * 128 + (k & 127) * 128 + (n & 127); }
         else if (i >= (int)m.o_wv && i < (int)m.o_bv) { const int k = i - (int)m.o_wv; off = 6ll * 128 * 128 + k * 32; nh = 2; }
         else if (i >= (int)m.o_wa && i < (int)m.o_ba) { const int u = i - (int)m.o_wa, k = u / m.A, a = u - k * m.A; off = 6ll * 128 * 128 + k * 32 + 1 + a; nh = 2; }
-        if (i < nP && off >= 0) {
+        const bool live = i < nP && off >= 0;
+        float psum = 0.0f;
+        if (live) {
             const float *p = slab + off;
             const long long ss = (long long)BIG_DW_TILES * 128 * 128, hs = 128 * 128;
-            float gsum = 0.0f;
-            int sl = 0;
-            if (nh == 1) {
-                for (; sl + 8 <= KS; sl += 8) {                        // eight partials in flight, added in slice order
-                    float v[8];
+            const int NPART = nh * KS, per = (NPART + 3) >> 2;
+            int q = part * per;
+            const int q1 = q + per < NPART ? q + per : NPART;
+            auto addr = [&](int qq) { return nh == 1 ? p + qq * ss : p + (qq >> 1) * ss + (qq & 1) * hs; };
+            for (; q + 8 <= q1; q += 8) {                          // eight partials in flight, added in order
+                float v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = p[(sl + u) * ss];
+                for (int u = 0; u < 8; ++u) v[u] = *addr(q + u);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) gsum = gsum + v[u];
-                }
-                for (; sl < KS; ++sl) gsum = gsum + p[sl * ss];
-            } else {
-                for (; sl + 4 <= KS; sl += 4) {                        // (slice, half) in order
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { v[2 * u] = p[(sl + u) * ss]; v[2 * u + 1] = p[(sl + u) * ss + hs]; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) gsum = gsum + v[u];
-                }
-                for (; sl < KS; ++sl) gsum = (gsum + p[sl * ss]) + p[sl * ss + hs];
+                for (int u = 0; u < 8; ++u) psum = psum + v[u];
             }
-            big_apply<BF>(m, i, gsum, grad, ad, co);
+            for (; q < q1; ++q) psum = psum + *addr(q);
         }
+        // (every lane takes part in the shuffles: the four lanes of an element are live or dead together)
+        const float s01 = psum + __shfl_down(psum, 1, 64);
+        const float gsum = s01 + __shfl_down(s01, 2, 64);
+        if (live && part == 0) big_apply<BF>(m, i, gsum, grad, ad, co);
     } else {
         const int lane = threadIdx.x & 63;
         const int e = ((int)blockIdx.x - wblocks) * 4 + (threadIdx.x >> 6);          // bias element: b1 | b2 | bv, ba

@@ -608,7 +608,7 @@ void launch_big_dw(hipStream_t s, const NetDims &m, const float *px, const float
     rps = (rps + 63) / 64 * 64;                                       // whole row tiles per slice (rows >= B carry zero gradients)
     const int ks_used = (Bp64 + rps - 1) / rps;
     DQN_LAUNCH(k_big_dw, dim3(ks_used, DW_TILES), dim3(256), 0, s, m, px, ph1, ph2, pdz1, pdz2, pdz3, Bp64, rps, slab);
-    const int wblocks = (int)((m.P + 255) / 256), bblocks = (2 * BH + 1 + m.A + 3) / 4;
+    const int wblocks = (int)((4 * m.P + 255) / 256), bblocks = (2 * BH + 1 + m.A + 3) / 4;
     DQN_LAUNCH((k_big_reduce<false>), dim3(wblocks + bblocks), dim3(256), 0, s, m, slab, ks_used, colsum, Bp64 / 64, B, grad, loss_part, loss_out, st,
                bump_ctr, adam, wblocks);
 }

@@ -377,7 +377,7 @@ void launch_big16_dw(hipStream_t s, const NetDims &m, const float *px, const flo
     const int ks_used = (Bp64 + rps - 1) / rps;
     auto bf = [](const float *p) { return reinterpret_cast<const __bf16 *>(p); };
     DQN_LAUNCH(k_big_dw16, dim3(ks_used, BIG_DW_TILES), dim3(256), 0, s, bf(px), bf(ph1), bf(ph2), bf(pdz1), bf(pdz2), bf(pdz3), Bp64, rps, slab);
-    const int wblocks = (int)((m.P + 255) / 256), bblocks = (2 * HB + 1 + m.A + 3) / 4;
+    const int wblocks = (int)((4 * m.P + 255) / 256), bblocks = (2 * HB + 1 + m.A + 3) / 4;
     DQN_LAUNCH((k_big_reduce<true>), dim3(wblocks + bblocks), dim3(256), 0, s, m, slab, ks_used, colsum, Bp64 / 64, B, grad, loss_part, loss_out, st,
                bump_ctr, adam, wblocks);
 }
