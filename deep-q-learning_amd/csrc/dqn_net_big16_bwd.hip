@@ -44,6 +44,18 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row0 = tile * 64;
     unsigned long long m1 = 0ull, m2 = 0ull;           // ReLU gates of this lane's accumulator elements: bit (rt*2 + ct)*16 + r
+    // the TD rule's per-row inputs (thread = row, tid < 64): asked for at the top of the tile, a whole forward pass before they are
+    // used (the stamps had the TD block at 8.4 K cycles: four dependent global round trips per row)
+    int td_a = 0; float td_r = 0.0f, td_d = 0.0f, td_w = 1.0f, td_nq[4] = {0.f, 0.f, 0.f, 0.f}, td_nt[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.do_bwd && tid0 < 64 && row0 + tid0 < B) {
+        const int i = row0 + tid0;
+        td_a = g.g.a ? g.g.a[i] : 0;
+        if (!g.g.targets) {
+            td_r = g.g.r[i]; td_d = g.g.d_f32 ? g.g.d_f32[i] : (g.g.d_u8[i] ? 1.0f : 0.0f);      // preprocessing :84
+            if (g.npass != 3 && A <= 4) for (int k2 = 0; k2 < A; ++k2) { td_nq[k2] = g.g.nq[(long long)i * A + k2]; td_nt[k2] = g.g.nt[(long long)i * A + k2]; }
+        }
+        td_w = g.g.w_raw ? g.g.w_raw[i] : (g.g.isw ? g.g.isw[i] : 1.0f);
+    }
     for (int ps = 0; ps < g.npass; ++ps) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                  // opaque per pass (keeps the epilogue addresses out of the outer loops)
@@ -183,7 +195,8 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
     BigLayer16<1, 1, true> LA; BigLayer16<HB / 32, 4, false> LB;
     LA.init(bpack + d16.p_wht, ct0, lane); LA.prefetch();
     LB.init(bpack + d16.p_w2t, ct0, lane);
-    for (int t = tid; t < 64 * S3; t += 256) l3[t] = (__bf16)0.0f;
+#pragma unroll
+    for (int u = 0; u < (64 * S3 / 2) / 256; ++u) reinterpret_cast<unsigned *>(l3)[tid + 256 * u] = 0u;      // (no runtime loop: no vmcnt(0) in front of it)
     LDS_BARRIER();
     if (tid < 64) {
         const int i = row0 + tid;
@@ -191,21 +204,21 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
         if (i < B) {
             float qr[16], tr[16], nqr[16], ntr[16];
             for (int k2 = 0; k2 < A; ++k2) qr[k2] = lq[(pl * 64 + tid) * 16 + k2];
-            const int ai = bw.a ? bw.a[i] : 0;
+            const int ai = td_a;
             if (bw.targets) {
                 for (int k2 = 0; k2 < A; ++k2) tr[k2] = bw.targets[(long long)i * A + k2];
             } else {
                 if (g.npass == 3) { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = lq[(0 * 64 + tid) * 16 + k2]; ntr[k2] = lq[(1 * 64 + tid) * 16 + k2]; } }
-                else { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = bw.nq[(long long)i * A + k2]; ntr[k2] = bw.nt[(long long)i * A + k2]; } }   // (k_big_fwd16 wrote them)
-                const float ri = bw.r[i];
-                const float di = bw.d_f32 ? bw.d_f32[i] : (bw.d_u8[i] ? 1.0f : 0.0f);     // preprocessing :84
+                else if (A <= 4) { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = td_nq[k2 & 3]; ntr[k2] = td_nt[k2 & 3]; } }                  // (k_big_fwd16 wrote them)
+                else { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = bw.nq[(long long)i * A + k2]; ntr[k2] = bw.nt[(long long)i * A + k2]; } }
+                const float ri = td_r, di = td_d;
                 const float delta = td_row(qr, nqr, ntr, ai, ri, di, bw.gamma, A, tr);
                 if (bw.td) bw.td[i] = delta;
                 if (bw.td_abs) bw.td_abs[i] = fabsf(delta);
             }
             float w = 1.0f;
-            if (bw.w_raw) { w = __fdiv_rn(bw.w_raw[i], g.st->wmax); if (bw.isw_out) bw.isw_out[i] = w; }
-            else if (bw.isw) w = bw.isw[i];
+            if (bw.w_raw) { w = __fdiv_rn(td_w, g.st->wmax); if (bw.isw_out) bw.isw_out[i] = w; }
+            else if (bw.isw) w = td_w;
             const float invB = __fdiv_rn(1.0f, (float)B);
             float gk[16], gsum = 0.0f;
             for (int k2 = 0; k2 < A; ++k2) {
@@ -225,12 +238,11 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
         lrow[tid] = rowloss;
     }
     LDS_BARRIER();
-    if (tid == 0) {                                    // per-tile loss, 16-row sub-tiles in order (as the 16-row kernels)
-        for (int q4 = 0; q4 < 4; ++q4) {
-            float s = 0.0f;
-            for (int k = 0; k < 16; ++k) s = s + lrow[16 * q4 + k];
-            bw.loss_part[4 * tile + q4] = s;
-        }
+    if (tid < 4) {                                     // per-tile loss, 16-row sub-tiles in order (as the 16-row kernels), one lane each
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = s + lrow[16 * tid + k];
+        bw.loss_part[4 * tile + tid] = s;
     }
     float *cs = g.colsum + (long long)tile * (2 * HB + 16);
     if (tid < 16) {                                    // column sums of dz3 (the values the weight gradient sees)
