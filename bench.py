@@ -364,7 +364,7 @@ def visible_gpu_count():
 
 def cnn_dp_line(dq, rank, world, dist):
     """BASELINE configs[4] in its multi-GPU form: every rank a full CNN learner on its own minibatch of 512 frame
-    stacks, ONE gradient exchange per update on the handle's own RCCL communicator -- the 6.4 MB fc leaf on the side stream
+    stacks, ONE gradient exchange per update on the handle's own RCCL communicator -- the 6.4 MB fc leaf on the communicator's own stream
     beside the rest of the backward, the 0.3 MB of small leaves behind it -- AdamW with grad_scale = 1 / world. The communicator
     is first checked against torch.distributed's all-reduce; any failure on any rank drops the line on every rank."""
     Bc, A_ = 512, 6

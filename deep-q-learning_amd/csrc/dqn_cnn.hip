@@ -944,7 +944,7 @@ struct dqn_cnn_handle {
     int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
     int env_n = 0; uint64_t env_seed = 0; long long env_steps = 0; const uint8_t *env_cur = nullptr;   // dqn_cnn_env_*_synth
     void *comm = nullptr; int rank = 0, world = 1;     // dqn_cnn_comm_init: per-GPU learners, one gradient all-reduce per update
-    hipEvent_t ev_fc = nullptr;                        // the fc leaf's all-reduce on the side stream (data-parallel update)
+    hipStream_t comm_st = nullptr; hipEvent_t ev_fc = nullptr, ev_fc_done = nullptr;   // the fc leaf's all-reduce on a stream of its own (data-parallel update)
 };
 
 struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
@@ -1047,6 +1047,8 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (h->side_kept) h->side = h->side_kept;
     dqn_rccl_comm_destroy(h->comm);
     if (h->ev_fc) (void)hipEventDestroy(h->ev_fc);
+    if (h->ev_fc_done) (void)hipEventDestroy(h->ev_fc_done);
+    if (h->comm_st) (void)hipStreamDestroy(h->comm_st);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
@@ -1244,10 +1246,15 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
         fc_done = true;
     }
     // data-parallel learners: the fc weight leaf is 95 % of the gradient (6.4 MB) and final here (one slice: its dW kernel wrote it
-    // straight into the gradient buffer) -- its all-reduce is issued NOW on the side stream, so that the message whose xGMI
+    // straight into the gradient buffer) -- its all-reduce is issued NOW on the communicator's own stream (behind an event of the
+    // side stream, so neither the dW kernels that follow there nor the backward-data chain wait for it): the message whose xGMI
     // bandwidth matters travels beside conv3 / conv2 / conv1's backward; the small leaves follow after the reduction
-    if (fc_reduced && h->comm && h->world > 1 && h->side && dw_slices(h, 3, B) == 1) {
-        if (dqn_rccl_allreduce_sum_f32(h->comm, h->grad + h->L[3].o_w, (size_t)h->L[3].K * h->L[3].N, sd) == DQN_OK) *fc_reduced = 1;
+    if (fc_reduced && h->comm && h->world > 1 && h->side && h->comm_st && dw_slices(h, 3, B) == 1) {
+        (void)hipEventRecord(h->ev_fc, sd); (void)hipStreamWaitEvent(h->comm_st, h->ev_fc, 0);
+        if (dqn_rccl_allreduce_sum_f32(h->comm, h->grad + h->L[3].o_w, (size_t)h->L[3].K * h->L[3].N, h->comm_st) == DQN_OK) {
+            *fc_reduced = 1;
+            (void)hipEventRecord(h->ev_fc_done, h->comm_st);
+        }
     }
     launch_dw<TC, TC, 2>(h, sd, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
     launch_bwd_data<TC, 2>(h, s, B);
@@ -1332,6 +1339,8 @@ extern "C" int dqn_cnn_comm_init(dqn_cnn_handle *h, const void *unique_id_128, i
     int rc = dqn_rccl_comm_init(&h->comm, unique_id_128, rank, world); if (rc) return rc;
     h->rank = rank; h->world = world;
     if (!h->ev_fc) (void)hipEventCreateWithFlags(&h->ev_fc, hipEventDisableTiming);
+    if (!h->ev_fc_done) (void)hipEventCreateWithFlags(&h->ev_fc_done, hipEventDisableTiming);
+    if (!h->comm_st && hipStreamCreateWithFlags(&h->comm_st, hipStreamNonBlocking) != hipSuccess) h->comm_st = nullptr;
     return DQN_OK;
 }
 extern "C" int dqn_cnn_comm_count_host(dqn_cnn_handle *h, int32_t *ranks) {
@@ -1376,6 +1385,7 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
         int fc_reduced = 0;
         if (h->bf16) cnn_backward_t<__bf16>(h, s, h->q[0], nullptr, isw, B, st, false, td, &fc_reduced); else cnn_backward_t<float>(h, s, h->q[0], nullptr, isw, B, st, false, td, &fc_reduced);
         CNN_TRY(hipGetLastError());
+        if (fc_reduced) (void)hipStreamWaitEvent(st, h->ev_fc_done, 0);                              // the fc leaf's sum has landed
         rc = dqn_cnn_allreduce_grads(h, fc_reduced, stream); if (rc) return rc;
         hipLaunchKernelGGL(k_cnn_opt_prep, dim3(1), dim3(1), 0, st, h->opt, h->b1, h->b2);      // step counters (the single-learner route does it beside the backward)
         rc = cnn_adam(h, 1.0f / (float)h->world, st, false); if (rc) return rc;
@@ -1536,6 +1546,7 @@ extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, cons
                                      float *td_abs_out, float *loss_host, void *stream) {
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(idx && B >= 1 && B <= h->max_batch, "bad argument");
+    CNN_REQ(h->env_cur != h->stage_s2, "the synthetic envs' reset frames still sit in the staging buffer: take one dqn_cnn_env_step_synth before the first update");
     int rc = dqn_cnn_replay_gather(h, idx, B, n_step, n_envs, gamma, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
     float gn = gamma;
     for (int k = 1; k < n_step; ++k) gn = gn * gamma;                  // gamma^n as n - 1 f32 products

@@ -661,7 +661,7 @@ k_per_top(DqnState *st, float *tree, int L) {
 // Traffic at L = 20 with every segment touched: 4 MB leaves in, 4 + 4 MB out, 8 B per item -- independent of the tree depth.
 #define PWS_LOG 11
 #define PWS_MIN_B 1024              // below: the wave-per-64-positions kernel (touched paths only) + k_per_top (measured: 10.3 vs 11.0 us per call at B = 1 024, 10.6 vs 16.8 at 8 192, 14.3 vs 517 at 2^20)
-#define PWS_MAX_ROOT_LOG 13          // at most 2^13 segment roots in the top kernel's LDS heap (L <= 24)
+#define PWS_MAX_ROOT_LOG 12          // at most 2^12 segment roots in the top kernel's LDS heap (32 KB; L <= 23; deeper trees: the chunk kernels)
 
 __global__ void __launch_bounds__(256)
 k_per_write_seg(float *__restrict__ tree, int L, const int32_t *__restrict__ idx, const float *__restrict__ val, int B,

@@ -293,7 +293,7 @@ int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const 
 int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream);
 /* Per-GPU learners for the CNN (BASELINE configs[4] in its 8-GPU form): the handle's own RCCL communicator (unique id from
  * dqn_comm_unique_id on rank 0). With it dqn_cnn_update / dqn_cnn_update_replay sum the gradient over the ranks -- the fc weight leaf
- * (6.4 MB of the 6.7 MB) on the handle's side stream beside the rest of the backward -- and step with grad_scale = 1 / world.
+ * (6.4 MB of the 6.7 MB) on a stream of the communicator's own beside the rest of the backward -- and step with grad_scale = 1 / world.
  * dqn_cnn_allreduce_grads: the same reduction as a call of its own, between dqn_cnn_grads and dqn_cnn_optimizer_step. */
 int dqn_cnn_comm_init(dqn_cnn_handle *h, const void *unique_id_128, int32_t rank, int32_t world);
 int dqn_cnn_comm_count_host(dqn_cnn_handle *h, int32_t *ranks);
