@@ -192,9 +192,13 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
     const BwdArgs &bw = g.g;
     const __bf16 *bpack = reinterpret_cast<const __bf16 *>(bw.pack);
     const int pl = g.npass - 1;                        // pass that produced q = pred
-    BigLayer16<1, 1, true> LA; BigLayer16<HB / 32, 4, false> LB;
+#ifndef BIG16_BWD_W2T_PF
+#define BIG16_BWD_W2T_PF 4              // (8 = ALL of W2^T in registers, requested before the tile's stash stores: measured equal -- 164 vs 161 us
+#endif                                  //  at B = 2^17, 458 vs 442 registers -- so the refills behind the dz2 stash are not what the product waits for)
+    BigLayer16<1, 1, true> LA; BigLayer16<HB / 32, BIG16_BWD_W2T_PF, false> LB;
     LA.init(bpack + d16.p_wht, ct0, lane); LA.prefetch();
     LB.init(bpack + d16.p_w2t, ct0, lane);
+    if (BIG16_BWD_W2T_PF == HB / 32) LB.prefetch();
 #pragma unroll
     for (int u = 0; u < (64 * S3 / 2) / 256; ++u) reinterpret_cast<unsigned *>(l3)[tid + 256 * u] = 0u;      // (no runtime loop: no vmcnt(0) in front of it)
     LDS_BARRIER();
@@ -270,7 +274,7 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
     {
         f32x16 acc[2][2];
         zero_acc16(acc);
-        LB.prefetch();                                 // W2^T's first k-blocks travel behind dz2
+        if (BIG16_BWD_W2T_PF != HB / 32) LB.prefetch();                                 // W2^T's first k-blocks travel behind dz2
         LA.run(l3, S3, lane, acc);
         LDS_BARRIER();                                 // (heads / Q are long done with h2: dz2 replaces it)
 #pragma unroll
