@@ -46,6 +46,7 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
     unsigned long long m1 = 0ull, m2 = 0ull;           // ReLU gates of this lane's accumulator elements: bit (rt*2 + ct)*16 + r
     // the TD rule's per-row inputs (thread = row, tid < 64): asked for at the top of the tile, a whole forward pass before they are
     // used (the stamps had the TD block at 8.4 K cycles: four dependent global round trips per row)
+    float td_wmax = 1.0f;
     int td_a = 0; float td_r = 0.0f, td_d = 0.0f, td_w = 1.0f, td_nq[4] = {0.f, 0.f, 0.f, 0.f}, td_nt[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.do_bwd && tid0 < 64 && row0 + tid0 < B) {
         const int i = row0 + tid0;
@@ -55,6 +56,7 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
             if (g.npass != 3 && A <= 4) for (int k2 = 0; k2 < A; ++k2) { td_nq[k2] = g.g.nq[(long long)i * A + k2]; td_nt[k2] = g.g.nt[(long long)i * A + k2]; }
         }
         td_w = g.g.w_raw ? g.g.w_raw[i] : (g.g.isw ? g.g.isw[i] : 1.0f);
+        if (g.g.w_raw) td_wmax = g.st->wmax;
     }
     for (int ps = 0; ps < g.npass; ++ps) {
         int tid = tid0;
@@ -184,6 +186,7 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
         LDS_BARRIER();
     }
     if (!g.do_bwd) continue;
+    STAMP(1, 12);
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, h = lane >> 5, c = lane & 31;
@@ -202,65 +205,101 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
 #pragma unroll
     for (int u = 0; u < (64 * S3 / 2) / 256; ++u) reinterpret_cast<unsigned *>(l3)[tid + 256 * u] = 0u;      // (no runtime loop: no vmcnt(0) in front of it)
     LDS_BARRIER();
-    if (tid < 64) {
+    STAMP(1, 13);
+    // the TD rule, one row per thread of wave 0; AM = the unrolled action bound (A <= 4 is the common case: four predicated
+    // steps instead of sixteen -- the stamps had this block at 7 K cycles of select chains on the 16-wide form)
+    auto td_block = [&](auto am_c) {
+        constexpr int AM = decltype(am_c)::value;
         const int i = row0 + tid;
         float rowloss = 0.0f;
         if (i < B) {
-            float qr[16], tr[16], nqr[16], ntr[16];
-            for (int k2 = 0; k2 < A; ++k2) qr[k2] = lq[(pl * 64 + tid) * 16 + k2];
+            float qr[AM], tr[AM], nqr[AM], ntr[AM];
+#pragma unroll
+            for (int k2 = 0; k2 < AM; ++k2) qr[k2] = k2 < A ? lq[(pl * 64 + tid) * 16 + k2] : 0.0f;
             const int ai = td_a;
             if (bw.targets) {
-                for (int k2 = 0; k2 < A; ++k2) tr[k2] = bw.targets[(long long)i * A + k2];
+#pragma unroll
+                for (int k2 = 0; k2 < AM; ++k2) tr[k2] = k2 < A ? bw.targets[(long long)i * A + k2] : 0.0f;
             } else {
-                if (g.npass == 3) { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = lq[(0 * 64 + tid) * 16 + k2]; ntr[k2] = lq[(1 * 64 + tid) * 16 + k2]; } }
-                else if (A <= 4) { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = td_nq[k2 & 3]; ntr[k2] = td_nt[k2 & 3]; } }                  // (k_big_fwd16 wrote them)
-                else { for (int k2 = 0; k2 < A; ++k2) { nqr[k2] = bw.nq[(long long)i * A + k2]; ntr[k2] = bw.nt[(long long)i * A + k2]; } }
-                const float ri = td_r, di = td_d;
-                const float delta = td_row(qr, nqr, ntr, ai, ri, di, bw.gamma, A, tr);
+#pragma unroll
+                for (int k2 = 0; k2 < AM; ++k2) {
+                    nqr[k2] = ntr[k2] = 0.0f;
+                    if (k2 < A) {
+                        if (g.npass == 3) { nqr[k2] = lq[(0 * 64 + tid) * 16 + k2]; ntr[k2] = lq[(1 * 64 + tid) * 16 + k2]; }
+                        else if (AM <= 4) { nqr[k2] = td_nq[k2 & 3]; ntr[k2] = td_nt[k2 & 3]; }              // (k_big_fwd16 wrote them)
+                        else { nqr[k2] = bw.nq[(long long)i * A + k2]; ntr[k2] = bw.nt[(long long)i * A + k2]; }
+                    }
+                }
+                // q_learning_functions.py:55-60 (td_row of dqn_net_common.h, unrolled: first max wins, quirks Q3 / Q4)
+                float best = nqr[0], ntb = ntr[0], qa = qr[0];
+#pragma unroll
+                for (int k2 = 1; k2 < AM; ++k2) {
+                    if (k2 < A && nqr[k2] > best) { best = nqr[k2]; ntb = ntr[k2]; }
+                    if (k2 == ai) qa = qr[k2];
+                }
+                const float t1 = bw.gamma * ntb;
+                const float t2 = t1 - qa;
+                const float t3 = (1.0f - td_d) * t2;
+                const float delta = td_r + t3;
+#pragma unroll
+                for (int k2 = 0; k2 < AM; ++k2) tr[k2] = qr[k2] + delta * (k2 == ai ? 1.0f : 0.0f);
                 if (bw.td) bw.td[i] = delta;
                 if (bw.td_abs) bw.td_abs[i] = fabsf(delta);
             }
             float w = 1.0f;
-            if (bw.w_raw) { w = __fdiv_rn(td_w, g.st->wmax); if (bw.isw_out) bw.isw_out[i] = w; }
+            if (bw.w_raw) { w = __fdiv_rn(td_w, td_wmax); if (bw.isw_out) bw.isw_out[i] = w; }
             else if (bw.isw) w = td_w;
             const float invB = __fdiv_rn(1.0f, (float)B);
-            float gk[16], gsum = 0.0f;
-            for (int k2 = 0; k2 < A; ++k2) {
-                const float e = qr[k2] - tr[k2];                       // pred - target, pred == q   (:35)
-                rowloss = rowloss + huber(e);                          // :36
-                const float cc = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
-                gk[k2] = (w * cc) * invB;                              // dL/dpred
-                gsum = gsum + gk[k2];
-                if (bw.dq) bw.dq[(long long)i * A + k2] = gk[k2];
-                if (bw.targets_out) bw.targets_out[(long long)i * A + k2] = tr[k2];
+            float gk[AM], gsum = 0.0f;
+#pragma unroll
+            for (int k2 = 0; k2 < AM; ++k2) {
+                gk[k2] = 0.0f;
+                if (k2 < A) {
+                    const float e = qr[k2] - tr[k2];                   // pred - target, pred == q   (:35)
+                    rowloss = rowloss + huber(e);                      // :36
+                    const float cc = e > 1.0f ? 1.0f : (e < -1.0f ? -1.0f : e);
+                    gk[k2] = (w * cc) * invB;                          // dL/dpred
+                    gsum = gsum + gk[k2];
+                    if (bw.dq) bw.dq[(long long)i * A + k2] = gk[k2];
+                    if (bw.targets_out) bw.targets_out[(long long)i * A + k2] = tr[k2];
+                }
             }
             if (bw.w_raw || bw.isw) rowloss = w * rowloss;
             const float gmean = __fdiv_rn(gsum, (float)A);             // dueling backward: dv = sum g ; dadv = g - mean g
             l3[tid * S3 + 0] = (__bf16)gsum;
-            for (int k2 = 0; k2 < A; ++k2) l3[tid * S3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
+#pragma unroll
+            for (int k2 = 0; k2 < AM; ++k2) if (k2 < A) l3[tid * S3 + 1 + k2] = (__bf16)(gk[k2] - gmean);
         }
         lrow[tid] = rowloss;
-    }
+    };
+    if (tid < 64) { if (A <= 4) td_block(std::integral_constant<int, 4>{}); else td_block(std::integral_constant<int, 16>{}); }
     LDS_BARRIER();
-    if (tid < 4) {                                     // per-tile loss, 16-row sub-tiles in order (as the 16-row kernels), one lane each
+    // per-tile loss (16-row sub-tiles in order, as the 16-row kernels; wave 1) beside the column sums of dz3 (the values the weight
+    // gradient sees; wave 0: lane (col, quarter) adds 16 rows in order, quarters fold by two exchanges) and dz3 out (waves 2, 3)
+    float *cs = g.colsum + (long long)tile * (2 * HB + 16);
+    if (tid >= 64 && tid < 68) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s = s + lrow[16 * tid + k];
-        bw.loss_part[4 * tile + tid] = s;
+        for (int k = 0; k < 16; ++k) s = s + lrow[16 * (tid - 64) + k];
+        bw.loss_part[4 * tile + tid - 64] = s;
     }
-    float *cs = g.colsum + (long long)tile * (2 * HB + 16);
-    if (tid < 16) {                                    // column sums of dz3 (the values the weight gradient sees)
+    if (tid < 64) {
+        const int cc = tid & 15, qt = tid >> 4;
         float s = 0.0f;
-        for (int rl = 0; rl < 64; ++rl) s = s + (float)l3[rl * S3 + tid];
-        cs[2 * HB + tid] = s;
+#pragma unroll
+        for (int rl = 0; rl < 16; ++rl) s = s + (float)l3[(16 * qt + rl) * S3 + cc];
+        s = s + __shfl_xor(s, 16, 64);
+        s = s + __shfl_xor(s, 32, 64);
+        if (tid < 16) cs[2 * HB + tid] = s;
     }
-    if (tid < 128) {                                   // dz3 out, k-packed [B/8][16][8]: thread (g8, cc) one 16-byte piece
-        const int g8 = tid >> 4, cc = tid & 15;
+    if (tid >= 128) {                                  // dz3 out, k-packed [B/8][16][8]: thread (g8, cc) one 16-byte piece
+        const int g8 = (tid - 128) >> 4, cc = tid & 15;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = l3[(8 * g8 + j) * S3 + cc];
         *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(bw.pdz3) + ((long long)((row0 >> 3) + g8) * 16 + cc) * 8) = v;
     }
+    STAMP(1, 15);
     auto colsum64 = [&](const f32x16 &x0, const f32x16 &x1) -> float {
         float s = 0.0f;
 #pragma unroll
@@ -275,8 +314,10 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
         f32x16 acc[2][2];
         zero_acc16(acc);
         if (BIG16_BWD_W2T_PF != HB / 32) LB.prefetch();                                 // W2^T's first k-blocks travel behind dz2
+        STAMP(1, 16);
         LA.run(l3, S3, lane, acc);
         LDS_BARRIER();                                 // (heads / Q are long done with h2: dz2 replaces it)
+        STAMP(1, 17);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -301,13 +342,16 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
             const float s = colsum64(acc[0][ct], acc[1][ct]);
             if (h == 0) cs[HB + 32 * (ct0 + ct) + c] = s;
         }
+        STAMP(1, 18);
     }
     LDS_BARRIER();
+    STAMP(1, 19);
     // ---- dz1 = (dz2 . W2^T) * (h1 > 0)
     {
         f32x16 acc[2][2];
         zero_acc16(acc);
         LB.run(la, SA, lane, acc);
+        STAMP(1, 20);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -331,6 +375,7 @@ k_big_rows16_bwd(NetDims m, Dims16 d16, Big16Args g, int B) {
             const float s = colsum64(acc[0][ct], acc[1][ct]);
             if (h == 0) cs[32 * (ct0 + ct) + c] = s;
         }
+        STAMP(1, 31);
     }
     LDS_BARRIER();                                     // the next tile's first pass rewrites the images
     }   // row tiles
