@@ -14,7 +14,7 @@ PREC_F32, PREC_BF16 = 0, 1
 NET_ONLINE, NET_TARGET = 0, 1
 ENV_SYNTHETIC, ENV_CARTPOLE = 0, 1
 FLAG_NO_HANDOVER, FLAG_NO_ACTOR16, FLAG_BF16_F32_ACTOR, FLAG_BIG_ROWS, FLAG_PW_SEGMENTS, FLAG_PW_CHUNKS = 1, 2, 4, 8, 16, 32
-CNN_FLAG_FC_WIDE_TILE, CNN_FLAG_NO_SIDE_STREAM = 1, 2
+CNN_FLAG_FC_WIDE_TILE, CNN_FLAG_NO_SIDE_STREAM, CNN_FLAG_LAYERWISE_CONV = 1, 2, 4
 ABI_VERSION = 3
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
  BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,

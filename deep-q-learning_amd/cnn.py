@@ -30,7 +30,7 @@ class CnnEngine:
         self.param_count = n.value
 
     def set_flags(self, flags: int):
-        """diagnostics (tests): _lib.CNN_FLAG_FC_WIDE_TILE | CNN_FLAG_NO_SIDE_STREAM; results stay bit-identical"""
+        """diagnostics (tests): _lib.CNN_FLAG_FC_WIDE_TILE | CNN_FLAG_NO_SIDE_STREAM | CNN_FLAG_LAYERWISE_CONV; results stay bit-identical"""
         L.check(self.lib.dqn_cnn_set_flags(self.h, int(flags)))
 
     def comm_init_native(self):

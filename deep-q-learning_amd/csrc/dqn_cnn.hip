@@ -254,6 +254,8 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TI *__restrict__ in2, int im
     }
 }
 
+#include "dqn_cnn_trunk.h"
+
 // dueling head (dddqn.py:29-31) on the fc features [B][512]: 16 rows per workgroup, thread (row, j) runs the k-ascending fmaf
 // chain of output j (0 = val, 1.. = adv) from LDS images of the rows and of the j-major head weights [16][512];
 // Q = val + adv - mean(adv) with the restatement's order of additions.
@@ -779,7 +781,12 @@ k_cnn_reduce(CnnSegs segs, long long total_units, float *__restrict__ grad, cons
 // backward-data (BwdGeo), output-major heads
 struct CnnOffs { long long o_w[4], o_b[4], o_wv, o_bv, o_wa, o_ba, P; int A; };
 template <typename TC>
-struct CnnShadows { TC *wt[4]; TC *wb[4]; float *wh, *bh; };
+struct CnnShadows { TC *wt[4]; TC *wb[4]; float *wh, *bh; TC *wp; };
+// wp (bf16 mode): the three convolutions' weights once more, packed by MFMA fragment for k_cnn_trunk16 -- element (n, k) of layer l at
+// CNN_WP_OFF[l] + ((((n >> 5) * (K / 16) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7): the 64 lanes' 16-byte fragments of
+// (column tile, k-step) are 1 KB contiguous (as [N][K] they are 64 pieces of 64 different cache lines: the trunk kernel's 84
+// fragment loads per lane took longer than its three convolutions)
+constexpr int CNN_WP_OFF1 = 32 * 256, CNN_WP_OFF2 = CNN_WP_OFF1 + 64 * 512, CNN_WP_ELEMS = CNN_WP_OFF2 + 64 * 576;
 template <typename TC>
 __device__ __forceinline__ void scatter_shadows(const CnnOffs &o, const CnnShadows<TC> &sh, long long i, float v) {
     if (i >= o.o_wv) {
@@ -798,6 +805,8 @@ __device__ __forceinline__ void scatter_shadows(const CnnOffs &o, const CnnShado
     const int k = (int)(e / N), n = (int)(e - (long long)k * N);
     const float vf = (l == 0 && sizeof(TC) == 2) ? __fdiv_rn(v, 255.0f) : v;
     sh.wt[l][(long long)n * K + k] = (TC)vf;
+    if (sizeof(TC) == 2 && l < 3)
+        sh.wp[(l == 0 ? 0 : (l == 1 ? CNN_WP_OFF1 : CNN_WP_OFF2)) + ((((n >> 5) * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7)] = (TC)vf;
     if (l == 3) sh.wb[3][e] = (TC)v;
     else if (l == 2) { const int tap = k >> 6, ic = k & 63; sh.wb[2][(long long)ic * 576 + tap * 64 + n] = (TC)v; }
     else if (l == 1) {
@@ -926,6 +935,7 @@ struct dqn_cnn_handle {
     float *params[2] = {nullptr, nullptr};             // online, target (flat f32, HWIO leaf order)
     void *wt[2][4] = {{nullptr}};                      // forward shadows [N][K] of the four GEMM layers
     void *wb[2][4] = {{nullptr}};                      // backward-data shadows (BwdGeo; [1..3])
+    void *wp[2] = {nullptr, nullptr};                  // bf16 mode: conv weights packed by MFMA fragment (k_cnn_trunk16)
     float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads, output-major [16][512] (0 = val, 1.. = adv), biases [1 + A]
     void *act[4] = {nullptr};                          // layer outputs (kept for the backward)
     void *act_t[4] = {nullptr};                        // the target pass of dqn_cnn_update (runs beside the online pass)
@@ -979,7 +989,7 @@ static CnnOffs cnn_offs(const dqn_cnn_handle *h) {
 template <typename TC> static CnnShadows<TC> cnn_shadows(const dqn_cnn_handle *h, int which) {
     CnnShadows<TC> s{};
     for (int l = 0; l < 4; ++l) { s.wt[l] = (TC *)h->wt[which][l]; s.wb[l] = (TC *)h->wb[which][l]; }
-    s.wh = h->wh[which]; s.bh = h->bh[which];
+    s.wh = h->wh[which]; s.bh = h->bh[which]; s.wp = (TC *)h->wp[which];
     return s;
 }
 
@@ -1010,7 +1020,8 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
     }
     const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
-    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh) + 6 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
+    const size_t sz_wp = al((size_t)CNN_WP_ELEMS * 2);
+    size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh + sz_wp) + 6 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
     for (int l = 0; l < 4; ++l) total += 4 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
     if (e != hipSuccess) { delete h; return dqn_set_error(DQN_ERR_NOMEM, (std::string("hipMalloc: ") + hipGetErrorString(e)).c_str()); }
@@ -1019,7 +1030,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     for (int w = 0; w < 2; ++w) {
         h->params[w] = (float *)take(sz_params);
         for (int l = 0; l < 4; ++l) { h->wt[w][l] = take(sz_wt[l]); h->wb[w][l] = take(sz_wt[l]); }
-        h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh);
+        h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh); h->wp[w] = take(sz_wp);
     }
     h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
     for (int l = 0; l < 4; ++l) { h->act[l] = take(2 * sz_act[l]); h->act_t[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
@@ -1127,7 +1138,7 @@ extern "C" int dqn_cnn_sync_target(dqn_cnn_handle *h, void *stream) {
  * on the caller's stream instead of the handle's side stream. Both leave every result bit-identical. */
 extern "C" int dqn_cnn_set_flags(dqn_cnn_handle *h, int32_t flags) {
     CNN_REQ(h, "null handle");
-    CNN_REQ((flags & ~(DQN_CNN_FLAG_FC_WIDE_TILE | DQN_CNN_FLAG_NO_SIDE_STREAM)) == 0, "unknown dqn_cnn flag");
+    CNN_REQ((flags & ~(DQN_CNN_FLAG_FC_WIDE_TILE | DQN_CNN_FLAG_NO_SIDE_STREAM | DQN_CNN_FLAG_LAYERWISE_CONV)) == 0, "unknown dqn_cnn flag");
     (void)hipDeviceSynchronize();
     if (h->side && !h->side_kept) h->side_kept = h->side;
     h->side = (flags & DQN_CNN_FLAG_NO_SIDE_STREAM) ? nullptr : h->side_kept;
@@ -1156,19 +1167,31 @@ static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int 
 
 // one pass over B1 frame stacks from `frames` followed by B2 from `frames2` (B2 = 0: a plain forward); q: [B1 + B2][A]
 template <typename TC>
-static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act) {
+static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act, bool want_maps) {
     const float *P = h->params[which];
     const int B = B1 + B2;
     TC *a0 = (TC *)act[0], *a1 = (TC *)act[1], *a2 = (TC *)act[2], *a3 = (TC *)act[3];
-    launch_layer<uint8_t, TC, 0>(s, B, frames, frames2 ? frames2 : frames, B1, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
-    launch_layer<TC, TC, 1>(s, B, a0, a0, B, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
-    launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
+    bool fused = false;
+    if constexpr (sizeof(TC) == 2) {
+        if (!(h->flags & DQN_CNN_FLAG_LAYERWISE_CONV)) {           // r03: frames -> conv3's map in one persistent kernel
+            const TrunkArgs ta{frames, frames2 ? frames2 : frames, B1, B, (const __bf16 *)h->wp[which], (const __bf16 *)h->wp[which] + CNN_WP_OFF1, (const __bf16 *)h->wp[which] + CNN_WP_OFF2,
+                               P + h->L[0].o_b, P + h->L[1].o_b, P + h->L[2].o_b, want_maps ? (__bf16 *)a0 : nullptr, want_maps ? (__bf16 *)a1 : nullptr, (__bf16 *)a2};
+            const int npairs = (B + 1) / 2;
+            DQN_LAUNCH(k_cnn_trunk16, dim3((unsigned)(npairs < h->num_cus ? npairs : h->num_cus)), dim3(256), 0, s, ta);
+            fused = true;
+        }
+    }
+    if (!fused) {
+        launch_layer<uint8_t, TC, 0>(s, B, frames, frames2 ? frames2 : frames, B1, (const TC *)h->wt[which][0], P + h->L[0].o_b, a0);
+        launch_layer<TC, TC, 1>(s, B, a0, a0, B, (const TC *)h->wt[which][1], P + h->L[1].o_b, a1);
+        launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
+    }
     launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3, (h->flags & DQN_CNN_FLAG_FC_WIDE_TILE) != 0);
     hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
-static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr) {
+static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr, bool want_maps = true) {
     if (!act) act = h->act;
-    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act);
+    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act, want_maps); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act, want_maps);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
@@ -1188,7 +1211,7 @@ extern "C" int dqn_cnn_q_targets(dqn_cnn_handle *h, const uint8_t *s, const int3
     CNN_REQ(h && s && a && r && s2 && d && targets, "null argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
-    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], st);                             // :54
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], st, nullptr, false);                             // :54
     cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // :52, :53 in one pass: q rows [0, B) | [B, 2B)
     launch_td(st, h->q[0], h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, nullptr, gamma, B, h->A, targets, nullptr, nullptr, nullptr, h->scratch);
     CNN_TRY(hipGetLastError());
@@ -1373,7 +1396,7 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     int rc = DQN_OK;
     // the target pass (:54) runs on the side stream in its own activation buffers, beside the online pass over s and s' (:52, :53)
     if (h->side) { (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(h->side, h->ev_fork, 0); }
-    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t);
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t, false);
     if (h->side) (void)hipEventRecord(h->ev_tgt, h->side);
     cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // one pass; s's activations are rows [0, B)
     if (h->side) (void)hipStreamWaitEvent(st, h->ev_tgt, 0);
@@ -1407,7 +1430,8 @@ extern "C" int dqn_cnn_update(dqn_cnn_handle *h, const uint8_t *s, const int32_t
  * stream) as dqn_act */
 extern "C" int dqn_cnn_act(dqn_cnn_handle *h, const uint8_t *frames, int32_t n, float epsilon, uint64_t seed, uint64_t ctr, int32_t *actions, void *stream) {
     CNN_REQ(h && frames && actions, "null argument");
-    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, frames, n, h->q[0], stream); if (rc) return rc;
+    CNN_REQ(n >= 1 && n <= h->max_batch, "n exceeds max_batch");
+    cnn_forward_pair(h, DQN_NET_ONLINE, frames, n, nullptr, 0, h->q[0], (hipStream_t)stream, nullptr, false);      // (acting keeps no maps)
     launch_policy((hipStream_t)stream, h->q[0], n, h->A, epsilon, seed, ctr, actions, nullptr);
     CNN_TRY(hipGetLastError());
     return DQN_OK;
@@ -1510,7 +1534,7 @@ extern "C" int dqn_cnn_env_step_synth(dqn_cnn_handle *h, float epsilon, float p_
     hipStream_t st = (hipStream_t)stream;
     const int n = h->env_n;
     const long long pos = h->ring_counter % h->ring_cap;
-    int rc = dqn_cnn_forward(h, DQN_NET_ONLINE, h->env_cur, n, h->q[0], stream); if (rc) return rc;
+    cnn_forward_pair(h, DQN_NET_ONLINE, h->env_cur, n, nullptr, 0, h->q[0], (hipStream_t)stream, nullptr, false);
     hipLaunchKernelGGL(k_cnn_synth_step, dim3(2048), dim3(256), 0, st, h->env_cur, h->ring_s, h->ring_s2, h->ring_r, h->ring_d, pos, n,
                        h->env_seed, (unsigned long long)h->env_steps, p_done, h->q[0], h->A, epsilon, h->ring_a);
     CNN_TRY(hipGetLastError());

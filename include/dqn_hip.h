@@ -260,8 +260,9 @@ typedef struct dqn_cnn_handle dqn_cnn_handle;
 int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t precision, dqn_cnn_handle **out);
 int dqn_cnn_destroy(dqn_cnn_handle *h);
 /* diagnostics for the tests (results stay bit-identical): FC_WIDE_TILE = the bf16 mode's 128 x 128 fc tile (normally taken from
- * 8 192 rows) at every batch size; NO_SIDE_STREAM = everything in stream order on the caller's stream */
-enum dqn_cnn_flags { DQN_CNN_FLAG_FC_WIDE_TILE = 1, DQN_CNN_FLAG_NO_SIDE_STREAM = 2 };
+ * 8 192 rows) at every batch size; NO_SIDE_STREAM = everything in stream order on the caller's stream; LAYERWISE_CONV = the bf16
+ * mode's three convolutions as one kernel per layer (r02's) instead of the fused trunk kernel (r03) */
+enum dqn_cnn_flags { DQN_CNN_FLAG_FC_WIDE_TILE = 1, DQN_CNN_FLAG_NO_SIDE_STREAM = 2, DQN_CNN_FLAG_LAYERWISE_CONV = 4 };
 int dqn_cnn_set_flags(dqn_cnn_handle *h, int32_t flags);
 int dqn_cnn_param_count(const dqn_cnn_handle *h, int64_t *n);
 int dqn_cnn_set_params(dqn_cnn_handle *h, int which_net, const float *src, int src_is_host, void *stream);

@@ -487,6 +487,44 @@ def test_cnn_fc_wide_tile_bf16(dq, B):
     e.close()
 
 
+@pytest.mark.parametrize("B", [1, 2, 5, 37, 130, 515])
+def test_cnn_trunk_bitexact(dq, B):
+    """r03: k_cnn_trunk16 -- conv1, conv2, conv3 of the bf16 mode as one persistent kernel (frames by LDS-DMA, maps in LDS, all
+    weight fragments in registers) -- against the per-layer kernels (DQN_CNN_FLAG_LAYERWISE_CONV). Same MFMA, same k order per
+    output element, same epilogue: Q (conv3's map through fc + heads), the loss and EVERY gradient leaf (conv1's and conv2's
+    maps are read by the backward) must be BIT-IDENTICAL; odd B = a pair with one image, 515 = more pairs than CUs (the
+    persistent loop and its DMA prefetch). Then one whole Agent._step (paired online pass from two tensors + target pass)."""
+    import torch
+    e = dq.CnnEngine(num_actions=A, max_batch=B, precision="bf16")
+    rng = np.random.default_rng(900 + B)
+    P = make_params(70 + (B % 7))
+    frames = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+    targets = rng.normal(0, 1, (B, A)).astype(np.float32); isw = rng.uniform(0.2, 1.0, B).astype(np.float32)
+    res = {}
+    for name, flag in (("fused", 0), ("layerwise", dq._lib.CNN_FLAG_LAYERWISE_CONV)):
+        e.set_flags(flag)
+        e.set_params(P)
+        q = host(e.forward(frames)).copy()
+        loss = e.grads(frames, targets, isw); g = host(e.get_buffer("grad")).copy()
+        res[name] = (q, loss, g)
+    assert np.array_equal(res["fused"][0], res["layerwise"][0])
+    assert res["fused"][1] == res["layerwise"][1] and np.array_equal(res["fused"][2], res["layerwise"][2])
+    if B <= 37:
+        q64 = onp.cnn_forward(P, frames, A, np.float64)
+        assert np.max(np.abs(res["fused"][0] - q64)) <= 2e-2 * np.abs(q64).max()
+    if B in (5, 130):
+        s2 = rng.integers(0, 256, (B, 84, 84, 4), dtype=np.uint8)
+        a = rng.integers(0, A, B).astype(np.int32); r = rng.normal(0, 1, B).astype(np.float32); d = (rng.random(B) < 0.1).astype(np.float32)
+        outs = []
+        for flag in (0, dq._lib.CNN_FLAG_LAYERWISE_CONV):
+            e.set_flags(flag)
+            e.set_params(P); e.set_params(make_params(71), target=True); e.set_optimizer(lr=1e-3)
+            e.update(frames, a, r, s2, d, isw=isw, gamma=0.99)
+            outs.append(host(e.get_buffer("params")).copy())
+        assert np.array_equal(outs[0], outs[1])
+    e.close()
+
+
 def test_cnn_configs4_size_512(dq):
     """BASELINE configs[4]'s per-GPU size -- 512 frame stacks -- checked, not only timed.
     (a) exact-f32 forward of 512 stacks bit-identical to the C restatement (orc_cnn_forward) and 1e-5 of f64 on a subset;

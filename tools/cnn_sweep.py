@@ -30,12 +30,14 @@ def timed(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--json", default=None); ap.add_argument("--log2", type=int, nargs="+", default=[9, 11, 13, 15])
+    ap.add_argument("--precision", nargs="+", default=["bf16", "f32"]); ap.add_argument("--flags", type=int, default=0, help="dqn_cnn_set_flags (4 = per-layer convolutions)")
     a = ap.parse_args()
     rows = []
-    for prec in ("bf16", "f32"):
+    for prec in a.precision:
         for lb in a.log2:
             B = 1 << lb
             e = dq.CnnEngine(num_actions=6, max_batch=B, precision=prec)
+            if a.flags: e.set_flags(a.flags)
             P = torch.randn(e.param_count) * 0.02
             e.set_params(P); e.set_params(P, target=True)
             g = torch.Generator(device="cuda"); g.manual_seed(lb)
