@@ -1165,19 +1165,37 @@ static void launch_layer(hipStream_t s, int B, const TI *in, const TI *in2, int 
     }
 }
 
+// k_cnn_trunk16's description of one pass (bf16 mode)
+static TrunkJob trunk_job(const dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, void *const *act, bool want_maps) {
+    const float *P = h->params[which];
+    const __bf16 *wp = (const __bf16 *)h->wp[which];
+    return TrunkJob{frames, frames2 ? frames2 : frames, B1, B1 + B2, wp, wp + CNN_WP_OFF1, wp + CNN_WP_OFF2, P + h->L[0].o_b, P + h->L[1].o_b, P + h->L[2].o_b,
+                    want_maps ? (__bf16 *)act[0] : nullptr, want_maps ? (__bf16 *)act[1] : nullptr, (__bf16 *)act[2]};
+}
+// Agent._step's two passes in ONE trunk launch (bf16 mode): online over s | s' (maps kept for the backward), target over s'
+static bool cnn_trunk_both(dqn_cnn_handle *h, const uint8_t *s, const uint8_t *s2, int B, hipStream_t st) {
+    if (!h->bf16 || (h->flags & DQN_CNN_FLAG_LAYERWISE_CONV)) return false;
+    const TrunkJob on = trunk_job(h, DQN_NET_ONLINE, s, B, s2, B, h->act, true), tg = trunk_job(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->act_t, false);
+    const int p0 = B, p1 = (B + 1) / 2, total = p0 + p1;
+    const TrunkArgs ta{{on, tg}, p0, total};
+    DQN_LAUNCH(k_cnn_trunk16, dim3((unsigned)(total < h->num_cus ? total : h->num_cus)), dim3(256), 0, st, ta);
+    return true;
+}
 // one pass over B1 frame stacks from `frames` followed by B2 from `frames2` (B2 = 0: a plain forward); q: [B1 + B2][A]
 template <typename TC>
-static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act, bool want_maps) {
+static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act, bool want_maps, bool trunk_done = false) {
     const float *P = h->params[which];
     const int B = B1 + B2;
     TC *a0 = (TC *)act[0], *a1 = (TC *)act[1], *a2 = (TC *)act[2], *a3 = (TC *)act[3];
     bool fused = false;
     if constexpr (sizeof(TC) == 2) {
         if (!(h->flags & DQN_CNN_FLAG_LAYERWISE_CONV)) {           // r03: frames -> conv3's map in one persistent kernel
-            const TrunkArgs ta{frames, frames2 ? frames2 : frames, B1, B, (const __bf16 *)h->wp[which], (const __bf16 *)h->wp[which] + CNN_WP_OFF1, (const __bf16 *)h->wp[which] + CNN_WP_OFF2,
-                               P + h->L[0].o_b, P + h->L[1].o_b, P + h->L[2].o_b, want_maps ? (__bf16 *)a0 : nullptr, want_maps ? (__bf16 *)a1 : nullptr, (__bf16 *)a2};
-            const int npairs = (B + 1) / 2;
-            DQN_LAUNCH(k_cnn_trunk16, dim3((unsigned)(npairs < h->num_cus ? npairs : h->num_cus)), dim3(256), 0, s, ta);
+            if (!trunk_done) {
+                const TrunkJob job = trunk_job(h, which, frames, B1, frames2, B2, act, want_maps);
+                const int npairs = (B + 1) / 2;
+                const TrunkArgs ta{{job, job}, npairs, npairs};
+                DQN_LAUNCH(k_cnn_trunk16, dim3((unsigned)(npairs < h->num_cus ? npairs : h->num_cus)), dim3(256), 0, s, ta);
+            }
             fused = true;
         }
     }
@@ -1189,9 +1207,9 @@ static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, i
     launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3, (h->flags & DQN_CNN_FLAG_FC_WIDE_TILE) != 0);
     hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
-static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr, bool want_maps = true) {
+static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr, bool want_maps = true, bool trunk_done = false) {
     if (!act) act = h->act;
-    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act, want_maps); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act, want_maps);
+    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act, want_maps, trunk_done); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act, want_maps);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
@@ -1395,10 +1413,12 @@ static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a
     hipStream_t st = (hipStream_t)stream;
     int rc = DQN_OK;
     // the target pass (:54) runs on the side stream in its own activation buffers, beside the online pass over s and s' (:52, :53)
+    // (bf16 mode, r03: the convolutions of both passes are one launch; only the target's fc + heads go to the side stream)
+    const bool both = cnn_trunk_both(h, s, s2, B, st);
     if (h->side) { (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(h->side, h->ev_fork, 0); }
-    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t, false);
+    cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t, false, both);
     if (h->side) (void)hipEventRecord(h->ev_tgt, h->side);
-    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st);                                   // one pass; s's activations are rows [0, B)
+    cnn_forward_pair(h, DQN_NET_ONLINE, s, B, s2, B, h->q[0], st, nullptr, true, both);              // one pass; s's activations are rows [0, B)
     if (h->side) (void)hipStreamWaitEvent(st, h->ev_tgt, 0);
     // the TD rule (:55-60) is the first thing the head-backward kernel does with the three Q tensors
     const CnnTdArgs td{h->q[0] + (size_t)B * h->A, h->q[2], a, r, d, gamma, td_abs_out};

@@ -32,12 +32,18 @@ typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
 #define TSTAMP(S) STAMP(7, S)
 #endif
 
-struct TrunkArgs {
+struct TrunkJob {
     const uint8_t *f1, *f2; int images1, B;            // images 0 .. images1-1 from f1, the rest from f2 (the paired pass)
     const __bf16 *w0, *w1, *w2;                        // fragment-packed shadows (CnnShadows::wp; conv1's holds W / 255)
     const float *b0, *b1, *b2;
     __bf16 *a0, *a1, *a2;                              // conv1 / conv2 maps: nullptr = not wanted; conv3's is always written
 };
+// One launch runs up to two passes (Agent._step: the online net over s | s' and the target net over s'): the pairs of pass 0,
+// then those of pass 1, form ONE list that the workgroups walk with stride gridDim -- every workgroup gets the same number of
+// pairs (768 pairs on 256 CUs = 3 each), and fetches the other net's weight fragments when its next pair belongs to the other
+// pass. (Two launches cannot share a CU -- each workgroup owns the whole LDS and register file -- so the target pass on a side
+// stream ran BEHIND the online pass, not beside it.)
+struct TrunkArgs { TrunkJob j[2]; int pairs0, total; };
 
 constexpr int TR_FR = 84 * 84 * 4;                     // one frame stack
 constexpr int TR_U8 = TR_FR + 1024;                    // DMA target (1 KB slack: the last piece is a whole 1-KB wave instruction)
@@ -52,7 +58,7 @@ constexpr int TR_OFF_BF = TR_U8;
 constexpr int TR_OFF_A1 = TR_OFF_BF;
 constexpr int TR_OFF_A0 = TR_OFF_BF + TR_BF;
 constexpr int TR_OFF_B = TR_OFF_A0 + 2 * TR_IMG0;
-constexpr int TR_LDS = TR_OFF_B + 160 * 4;
+constexpr int TR_LDS = TR_OFF_B + 2 * 160 * 4;
 constexpr int TR_PF = 6;                               // operand reads in flight ahead of the MFMAs (register ring)
 static_assert(TR_OFF_A0 % 16 == 0 && TR_OFF_BF % 16 == 0 && 2 * TR_IMG1 <= TR_BF && TR_LDS <= 160 * 1024, "LDS carve");
 
@@ -86,26 +92,28 @@ __device__ __forceinline__ void trunk_out(const f32x16c &acc, const float (&bias
 }
 
 __global__ void __launch_bounds__(256)
-k_cnn_trunk16(TrunkArgs g) {
+k_cnn_trunk16(TrunkArgs ga) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[TR_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c = lane & 31, wm = wave & 1, wn = wave >> 1;
     float *lb = reinterpret_cast<float *>(lds + TR_OFF_B);
-    if (tid < 160) lb[tid] = tid < 32 ? g.b0[tid] : (tid < 96 ? g.b1[tid - 32] : g.b2[tid - 96]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)                        // (pass 1 absent: its pointers repeat pass 0's)
+        if (tid < 160) lb[160 * n + tid] = tid < 32 ? ga.j[n].b0[tid] : (tid < 96 ? ga.j[n].b1[tid - 32] : ga.j[n].b2[tid - 96]);
+    int net = (int)blockIdx.x >= ga.pairs0 ? 1 : 0;      // the pass of the current pair (set by the pass loop below)
     // biases of this lane's 16 accumulator elements (channel ch0 + 8 gq + u): read once per phase, before its first tile
     auto biases = [&](float (&bias)[16], int ch0) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const float4 bv = *reinterpret_cast<const float4 *>(lb + ch0 + 8 * gq);
+            const float4 bv = *reinterpret_cast<const float4 *>(lb + 160 * net + ch0 + 8 * gq);
             bias[4 * gq] = bv.x; bias[4 * gq + 1] = bv.y; bias[4 * gq + 2] = bv.z; bias[4 * gq + 3] = bv.w;
         }
     };
-    const int npairs = (g.B + 1) >> 1;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     // one image's frames: 28 pieces of 1 KB (wave instruction = 64 lanes x 16 B, LDS destination lane-linear), 7 per wave.
     // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin the compiler puts s_waitcnt vmcnt(0) in front of EVERY
     //  later LDS read -- the DMA may alias it -- and vmcnt(0) also waits for the map stores just issued: the stamps had 600 cycles
     //  per epilogue block, 4/5 of the kernel. The DMA's completion is waited for by hand: frames_landed.)
-    auto dma = [&](int image) {
+    auto dma = [&](const TrunkJob &g, int image) {
         image = image < g.B ? image : g.B - 1;
         const uint8_t *p = image < g.images1 ? g.f1 + (long long)image * TR_FR : g.f2 + (long long)(image - g.images1) * TR_FR;
 #pragma unroll
@@ -123,21 +131,27 @@ k_cnn_trunk16(TrunkArgs g) {
         __syncthreads();                                         // everyone's
     };
     TSTAMP(0);
-    if ((int)blockIdx.x < npairs) dma(2 * blockIdx.x);
+    if ((int)blockIdx.x < ga.total) dma(ga.j[net], 2 * ((int)blockIdx.x - (net ? ga.pairs0 : 0)));
     // the weights: fragment of channel c (+ 32 wn) for k-step s = 8 consecutive k at 16 s + 8 h, packed 1 KB per (column tile, step)
     bf16x8c w0r[16], w1r[32], w2r[36];
+    auto fetch_weights = [&](const TrunkJob &g) {
+        int lo = lane * 8;                             // opaque per call: the 84 addresses are formed here, next to their loads (hoisted
+        asm volatile("" : "+v"(lo));                   // out of the pass loop they were 28 spilled offsets, each reload a vmcnt(0))
+        const __bf16 *p0 = g.w0 + lo, *p1 = g.w1 + wn * (32 * 512) + lo, *p2 = g.w2 + wn * (36 * 512) + lo;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) w0r[s] = *reinterpret_cast<const bf16x8c *>(g.w0 + (s * 64 + lane) * 8);
+        for (int s = 0; s < 16; ++s) w0r[s] = *reinterpret_cast<const bf16x8c *>(p0 + s * 512);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) w1r[s] = *reinterpret_cast<const bf16x8c *>(g.w1 + ((wn * 32 + s) * 64 + lane) * 8);
+        for (int s = 0; s < 32; ++s) w1r[s] = *reinterpret_cast<const bf16x8c *>(p1 + s * 512);
 #pragma unroll
-    for (int s = 0; s < 36; ++s) w2r[s] = *reinterpret_cast<const bf16x8c *>(g.w2 + ((wn * 36 + s) * 64 + lane) * 8);
-    // conv1's and conv2's fragments are PINNED to accumulation registers (the MFMA reads its A operand from either file): left
-    // to itself the allocator parks them there as spills and copies every one (4 x v_accvgpr_mov) in front of its MFMA
+        for (int s = 0; s < 36; ++s) w2r[s] = *reinterpret_cast<const bf16x8c *>(p2 + s * 512);
+        // conv1's and conv2's fragments are PINNED to accumulation registers (the MFMA reads its A operand from either file):
+        // left to itself the allocator parks them there as spills and copies every one (4 x v_accvgpr_mov) in front of its MFMA
 #pragma unroll
-    for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(w0r[s]));
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(w0r[s]));
 #pragma unroll
-    for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(w1r[s]));
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(w1r[s]));
+    };
+
     // u8 frames (DMA target) -> the bf16 image: every pixel converted ONCE (integers 0..255 are exact in bf16; 1/255 is in the
     // weight shadow). Converting inside conv1's k-loop instead (each pixel is in 4 patches) made conv1 VALU-bound: 16 VALU
     // instructions per MFMA, 148 cycles per step by the stamps.
@@ -164,7 +178,7 @@ k_cnn_trunk16(TrunkArgs g) {
     // conv1 of one image: 13 row tiles of 32 (the last one half empty), tiles wave, wave + 4, ...
     // k = (kh, kw, ch): step s = row kh = s >> 1, pixels 4 (s & 1) + 2 h, + 1 = pair 2 ox + 2 (s & 1) + h
     auto off0 = [](int s) { return (s >> 1) * TR_BF_RS + 16 * (s & 1); };
-    auto conv1 = [&](int img, int imgG) {
+    auto conv1 = [&](const TrunkJob &g, int img, int imgG) {
         bf16x8c ring[TR_PF];
         int pos = 32 * wave + c, oy = pos / 20, ox = pos - 20 * oy;
         const unsigned char *ab = lds + TR_OFF_BF + (4 * oy) * TR_BF_RS + h * TR_BF_PL + ox * 16;
@@ -197,22 +211,34 @@ k_cnn_trunk16(TrunkArgs g) {
         }
     };
 
-    for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    int job = blockIdx.x;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {             // (a loop, not a conditional reload inside the pair loop: the fragment registers
+    const int end = pass == 0 ? ga.pairs0 : ga.total;  //  are rewritten unconditionally at its top -- the conditional form spilled)
+    if (job >= end) continue;
+    net = pass;
+    const TrunkJob &g = ga.j[pass];
+    fetch_weights(g);
+    for (; job < end; job += gridDim.x) {
+        const int pair = job - (pass ? ga.pairs0 : 0);
         TSTAMP(1);
         frames_landed();                               // image 0 in the DMA target; conv3 of the previous pair is done with its input
         TSTAMP(2);
         convert();
         LDS_BARRIER();
-        dma(2 * pair + 1);                             // image 1 travels behind conv1 of image 0
+        dma(g, 2 * pair + 1);                          // image 1 travels behind conv1 of image 0
         TSTAMP(3);
-        conv1(0, 2 * pair);
+        conv1(g, 0, 2 * pair);
         TSTAMP(4);
         frames_landed();
         convert();
         LDS_BARRIER();
-        if (pair + (int)gridDim.x < npairs) dma(2 * (pair + gridDim.x));       // the next pair's first image: behind everything below
+        {                                              // the next pair's first image: behind everything below
+            const int nj = job + (int)gridDim.x;
+            if (nj < ga.total) { const int nn = nj >= ga.pairs0 ? 1 : 0; dma(ga.j[nn], 2 * (nj - (nn ? ga.pairs0 : 0))); }
+        }
         TSTAMP(5);
-        conv1(1, 2 * pair + 1);
+        conv1(g, 1, 2 * pair + 1);
         TSTAMP(6);
         LDS_BARRIER();                                 // conv1's maps complete; the bf16 image is dead (conv2's map replaces it)
         TSTAMP(7);
@@ -289,5 +315,6 @@ k_cnn_trunk16(TrunkArgs g) {
             }
         }
         TSTAMP(10);
+    }
     }
 }
