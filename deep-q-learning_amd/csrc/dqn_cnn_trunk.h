@@ -217,7 +217,8 @@ k_cnn_trunk16(TrunkArgs ga) {
     const int end = pass == 0 ? ga.pairs0 : ga.total;  //  are rewritten unconditionally at its top -- the conditional form spilled)
     if (job >= end) continue;
     net = pass;
-    const TrunkJob &g = ga.j[pass];
+    const TrunkJob g = ga.j[pass];                     // BY VALUE, in scalar registers: through a reference every use of a field was an
+                                                       // s_load + lgkmcnt(0), which also drained the operand reads in flight (once per tile)
     fetch_weights(g);
     for (; job < end; job += gridDim.x) {
         const int pair = job - (pass ? ga.pairs0 : 0);

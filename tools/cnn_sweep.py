@@ -46,9 +46,9 @@ def main():
             act = torch.randint(0, 6, (B,), dtype=torch.int32, device="cuda", generator=g)
             r = torch.randn(B, device="cuda", generator=g); d = (torch.rand(B, device="cuda", generator=g) < 0.05).float()
             q = torch.empty((B, 6), dtype=torch.float32, device="cuda")
-            iters = max(2, 4096 // B * 4)
+            iters = max(8, 4096 // B * 4)
             fu = timed(lambda: e.forward(f1, out=q), iters)
-            uu = timed(lambda: e.update(f1, act, r, f2, d), max(2, iters // 3))
+            uu = timed(lambda: e.update(f1, act, r, f2, d), max(6, iters // 3))
             row = {"precision": prec, "B": B, "forward_us": round(fu, 1), "forward_TFs": round(FWD * B / fu / 1e6, 1), "forward_frac_of_mfma_peak": round(FWD * B / fu / 1e6 / PEAK[prec], 4),
                    "update_us": round(uu, 1), "update_TFs": round((3 * FWD + BWD) * B / uu / 1e6, 1), "update_frac_of_mfma_peak": round((3 * FWD + BWD) * B / uu / 1e6 / PEAK[prec], 4)}
             print(row, flush=True)
