@@ -65,10 +65,11 @@ class CnnVectorAgent:
             # the frame ring holds one row per env step; the n-step transition that starts at a row exists once its n - 1
             # successors do. So the PER index learns of step t - n + 1 when step t arrives (its own ring counter is n - 1 steps
             # behind: the same positions), and rows whose frames have just been overwritten are taken out of the draw until then.
-            if self.env_steps * n >= self.cnn.capacity:
-                self.index.per_set_sorted(self._pos + first, self._zero_prio)
-            if self.env_steps >= self.n_step - 1:
-                self.index.per_index_advance(n)
+            # (one launch: dqn_per_index_step; r02 / early r03: per_set_sorted(zeros) + per_index_advance = three launches and an index add)
+            zero_n = n if self.env_steps * n >= self.cnn.capacity else 0
+            adv = n if self.env_steps >= self.n_step - 1 else 0
+            if zero_n or adv:
+                self.index.per_index_step(adv, first, zero_n)
         self.env_steps += 1
         self.epsilon = max(self.epsilon * self.decay, self.min_eps)
 

@@ -15,7 +15,7 @@ NET_ONLINE, NET_TARGET = 0, 1
 ENV_SYNTHETIC, ENV_CARTPOLE = 0, 1
 FLAG_NO_HANDOVER, FLAG_NO_ACTOR16, FLAG_BF16_F32_ACTOR, FLAG_BIG_ROWS, FLAG_PW_SEGMENTS, FLAG_PW_CHUNKS = 1, 2, 4, 8, 16, 32
 CNN_FLAG_FC_WIDE_TILE, CNN_FLAG_NO_SIDE_STREAM, CNN_FLAG_LAYERWISE_CONV = 1, 2, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 (BUF_PARAMS, BUF_TARGET, BUF_MU, BUF_NU, BUF_GRAD, BUF_TREE, BUF_STATES, BUF_ACTIONS, BUF_REWARDS,
  BUF_OBSERVATIONS, BUF_DONES, BUF_BATCH_IDX, BUF_BATCH_ISW, BUF_BATCH_TD, BUF_LOSS, BUF_ENV_OBS,
  BUF_ENV_ACTIONS) = range(17)
@@ -89,6 +89,7 @@ SIGNATURES = {
     "dqn_cnn_env_reset_synth": [_P, _I32, C.c_uint64, _P],
     "dqn_cnn_env_step_synth": [_P, C.c_float, C.c_float, C.POINTER(_I64), _P],
     "dqn_per_index_advance": [_P, _I32, _P],
+    "dqn_per_index_step": [_P, _I32, _I64, _I32, _P],
     "dqn_cnn_comm_init": [_P, _P, _I32, _I32],
     "dqn_cnn_comm_count_host": [_P, C.POINTER(_I32)],
     "dqn_cnn_allreduce_grads": [_P, _I32, _P],

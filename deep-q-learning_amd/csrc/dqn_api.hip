@@ -390,6 +390,20 @@ extern "C" int dqn_per_index_advance(dqn_handle *h, int32_t n, void *stream) {
     return DQN_OK;
 }
 
+/* One launch per vector env step for a positions-only index whose rows are overwritten in place (the frame ring of configs[4]): the
+ * zero_n positions from zero_first on (mod capacity) get priority 0 -- out of the draw until their successors exist -- and then n new
+ * positions enter at the running max priority as in dqn_per_index_advance (n = 0: none). Same tree as dqn_per_set_sorted(zeros) +
+ * dqn_per_index_advance, which were three launches and a host-side index add. */
+extern "C" int dqn_per_index_step(dqn_handle *h, int32_t n, int64_t zero_first, int32_t zero_n, void *stream) {
+    REQUIRE(h, "null argument");
+    if (!h->cfg.use_per) return fail(DQN_ERR_STATE, "PER call on a handle created with use_per=0");
+    REQUIRE(n >= 0 && n <= h->cfg.capacity && zero_n >= 0 && zero_n <= h->cfg.capacity && zero_first >= 0 && (n > 0 || zero_n > 0),
+            "dqn_per_index_step: n=%d, zero_n=%d must be in [0, capacity], not both 0", n, zero_n);
+    launch_per_add((hipStream_t)stream, h->st, h->tree, h->Ntree, h->L, n, h->cfg.capacity, 1, zero_first, zero_n);
+    HIP_TRY(hipGetLastError());
+    return DQN_OK;
+}
+
 extern "C" int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter) {
     REQUIRE(h, "null argument");
     DqnState s;

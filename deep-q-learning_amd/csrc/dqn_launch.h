@@ -159,7 +159,7 @@ void launch_per_sample(hipStream_t st_, const DqnState *st, const float *tree, l
 // 1 = always the wave-per-chunk kernel, 2 = always the segment kernel (tests)
 void launch_per_write_sorted(hipStream_t st_, DqnState *st, float *tree, long long N, int L, const int32_t *idx,
                              const float *val, int B, int mode, float alpha, float eps, float *pw_part = nullptr, int force = 0);
-void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance = 0);
+void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance = 0, long long zero_first = 0, int zero_n = 0);
 void launch_isw_normalize(hipStream_t st_, const float *w_raw, int B, float *isw, DqnState *st, const unsigned int *wmax_bits);
 void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long long *stamp, long long N,
                       int L, const int32_t *idx, const float *val, int B, int mode, float alpha, float eps,

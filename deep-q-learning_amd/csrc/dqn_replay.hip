@@ -787,8 +787,18 @@ k_per_top_seg(DqnState *st, float *tree, int L, const float *__restrict__ pmax_p
 // ------------------------------------------------- leaf-range insert (ring add with PER)
 // device code: per_add_range_wg / per_add_slow in dqn_per_device.h
 __global__ void __launch_bounds__(1024)
-k_per_add(DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance) {
+k_per_add(DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance, long long zero_first, int zero_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // zero_n > 0 (dqn_per_index_step): the zero_n positions from zero_first on leave the draw first (priority 0: their rows are being
+    // overwritten) -- a consecutive leaf range like the insert's, so the same range code with the value 0
+    if (zero_n > 0) {
+        const long long z = zero_first % cap;
+        if (zero_n <= RANGE_MAX && z + zero_n <= cap) per_add_range_wg(tree, Nt, L, z, zero_n, 0.0f, lds);
+        else per_add_slow(tree, Nt, L, (unsigned long long)z, zero_n, 0.0f, cap);
+        __threadfence_block();
+        __syncthreads();
+        if (n <= 0) return;
+    }
     // advance = 0: the n slots have just been written (ring_counter is past them); 1 (dqn_per_index_advance): this launch IS the
     // add -- the slots start at ring_counter, committed by thread 0 once every thread has read it
     const unsigned long long c_base = advance ? st->ring_counter : st->ring_counter - (unsigned long long)n;
@@ -883,9 +893,9 @@ void launch_per_write(hipStream_t st_, DqnState *st, float *tree, unsigned long 
 
 static inline int pow2_threads(int n, int lo, int hi) { int t = lo; while (t < n && t < hi) t <<= 1; return t; }
 
-void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance) {
+void launch_per_add(hipStream_t st_, const DqnState *st, float *tree, long long Nt, int L, int n, long long cap, int advance, long long zero_first, int zero_n) {
     const size_t lds = sizeof(float) * 64;
-    hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n, 64, 1024)), lds, st_, const_cast<DqnState *>(st), tree, Nt, L, n, cap, advance);
+    hipLaunchKernelGGL(k_per_add, dim3(1), dim3(pow2_threads(n > zero_n ? n : zero_n, 64, 1024)), lds, st_, const_cast<DqnState *>(st), tree, Nt, L, n, cap, advance, zero_first, zero_n);
 }
 
 

@@ -201,6 +201,10 @@ class Engine:
         """the handle as a positions-only prioritized index: n new positions at the running max priority (no row data)"""
         L.check(self.lib.dqn_per_index_advance(self.h, int(n), self._s()))
 
+    def per_index_step(self, n, zero_first=0, zero_n=0):
+        """per_index_advance(n) preceded, in the same launch, by priority 0 for the zero_n positions from zero_first on (rows being overwritten)"""
+        L.check(self.lib.dqn_per_index_step(self.h, int(n), int(zero_first), int(zero_n), self._s()))
+
     def replay_size(self):
         size, ctr = C.c_int64(), C.c_int64()
         L.check(self.lib.dqn_replay_size_host(self.h, C.byref(size), C.byref(ctr)))

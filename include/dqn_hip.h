@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DQN_ABI_VERSION 3
+#define DQN_ABI_VERSION 4
 
 typedef enum {
     DQN_OK = 0,
@@ -121,6 +121,9 @@ int dqn_replay_add(dqn_handle *h, const float *s, const int32_t *a, const float 
                    const float *s2, const uint8_t *d, int32_t n, void *stream);
 /* the handle as a positions-only prioritized index: n new positions at the running max priority (counter, size, leaves), no row data */
 int dqn_per_index_advance(dqn_handle *h, int32_t n, void *stream);
+/* the same in one launch with rows that are being overwritten in place: the zero_n positions from zero_first on (mod capacity) get
+ * priority 0 first (out of the draw), then n new positions enter (n = 0: none) */
+int dqn_per_index_step(dqn_handle *h, int32_t n, int64_t zero_first, int32_t zero_n, void *stream);
 int dqn_replay_size_host(dqn_handle *h, int64_t *size, int64_t *counter);   /* synchronises */
 
 /* sample_batch (replay_buffer.py:68-85). idx_in != NULL: gather exactly those rows

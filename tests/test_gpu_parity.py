@@ -996,6 +996,33 @@ def test_tree_invariant_under_replay_stress(dq):
     e.close()
 
 
+@pytest.mark.parametrize("cap,n,steps", [(1 << 12, 256, 40), (3 * 512, 512, 11), (1 << 14, 2048, 20)])
+def test_per_index_step_equals_set_and_advance(dq, cap, n, steps):
+    """r03: dqn_per_index_step (ONE launch: the positions about to be overwritten leave the draw, then n new positions enter at the
+    running max priority) leaves the same tree, counter and size as dqn_per_set_sorted(zeros) + dqn_per_index_advance -- over ring
+    laps (the zeroed run and the inserted run wrap at different steps), with a lag of two steps between the two runs as in
+    CnnVectorAgent's 3-step loop, a non-power-of-two capacity, and n above the one-workgroup range path (2 048)."""
+    import torch
+    mk = lambda: dq.Engine(dq.EngineConfig(obs_dim=1, hidden1=16, hidden2=16, num_actions=2, capacity=cap, use_per=True, max_batch=n, seed=3))
+    a, b = mk(), mk()
+    pos = torch.arange(n, dtype=torch.int32, device=a.device); zeros = torch.zeros(n, dtype=torch.float32, device=a.device)
+    rng = np.random.default_rng(cap + n)
+    for t in range(steps):
+        first = (t * n) % cap
+        zero_n = n if t * n >= cap else 0
+        adv = n if t >= 2 else 0
+        if zero_n: a.per_set_sorted((pos + first) % cap if first + n > cap else pos + first, zeros)
+        if adv: a.per_index_advance(n)
+        if zero_n or adv: b.per_index_step(adv, first, zero_n)
+        if t % 3 == 2 and t >= 2:                                   # some priorities move in between, as the update's write-back does
+            k = np.sort(rng.choice(min((t - 1) * n, cap), 64, replace=False)).astype(np.int32); pr = rng.uniform(0.1, 3.0, 64).astype(np.float32)
+            a.per_update_sorted(k, pr); b.per_update_sorted(k, pr)
+        ta, tb = host(a.buffer(dq._lib.BUF_TREE)), host(b.buffer(dq._lib.BUF_TREE))
+        assert np.array_equal(ta, tb), t
+        assert a.replay_size() == b.replay_size()
+    a.close(); b.close()
+
+
 def test_per_set_sorted_equals_per_set(dq):
     """dqn_per_set_sorted (raw priorities through the many-CU sorted write-back) leaves the same tree as dqn_per_set, zeros
     included (rows taken out of the draw), and a later draw never returns a zeroed row"""

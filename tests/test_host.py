@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == bound, (set(declared) ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dqn_abi_version() == dq._lib.ABI_VERSION == 3
+    assert lib.dqn_abi_version() == dq._lib.ABI_VERSION == 4
     c = dq._lib.DqnConfig()
     lib.dqn_default_config(C.byref(c))                       # Test/lunar_lander.py:23-48 defaults
     assert (c.obs_dim, c.hidden1, c.hidden2, c.num_actions, c.capacity, c.max_batch) == (9, 32, 64, 4, 100000, 64)

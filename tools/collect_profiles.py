@@ -45,7 +45,14 @@ for part in ("bench", "big", "big16", "big16f", "bench16", "cnn", "cnnf32"):    
         mf.update({k: v for k, v in json.load(open(f2)).items() if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0})
 if mf:
     json.dump(mf, open(f"profiles/{rnd}_pmc_mfma.json", "w"), indent=1)
-for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"), (f"gpurun_out/cnn_{tag}.txt", f"profiles/{rnd}_cnn_kernels.txt"), (f"gpurun_out/cnn_sweep_{tag}.json", f"profiles/{rnd}_cnn_sweep.json"),
+tk = {}
+for f2 in (f"gpurun_out/pmcm_{tag}_trunk.json", f"gpurun_out/pmcl_{tag}_trunk.json"):          # the CNN trunk kernel: wave-state + LDS counters, B = 2048
+    if os.path.exists(f2):
+        for k, v in json.load(open(f2)).items():
+            if k.startswith("k_cnn_trunk"): tk.setdefault(k, {}).update(v)
+if tk:
+    json.dump(tk, open(f"profiles/{rnd}_pmc_trunk.json", "w"), indent=1)
+for src, dst in ((f"gpurun_out/bench_{tag}.json", f"profiles/{rnd}_bench_under_rocprof.json"), (f"gpurun_out/cnn_{tag}.txt", f"profiles/{rnd}_cnn_kernels.txt"), (f"gpurun_out/cnn_sweep_{tag}.json", f"profiles/{rnd}_cnn_sweep.json"), (f"gpurun_out/cnn_sweep_{tag}_layerwise.json", f"profiles/{rnd}_cnn_sweep_layerwise_conv.json"),
                  (f"gpurun_out/probe_{tag}.json", f"profiles/{rnd}_per_sample_probe.json"), (f"gpurun_out/wprobe_{tag}.json", f"profiles/{rnd}_per_write_probe.json"),
                  (f"gpurun_out/pmcw_{tag}.json", f"profiles/{rnd}_pmc_per_write.json")):
     if os.path.exists(src):

@@ -19,6 +19,9 @@ bash $R/tools/prof_pmc_mfma.sh ${tag}_bench16 $R/bench.py --steps 200 --warmup 2
 bash $R/tools/prof_pmc_write.sh $tag 2>&1 | tail -8
 bash $R/tools/prof_pmc_mfma.sh ${tag}_cnn $R/tools/cnn_probe.py --mode update --reps 6 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
 bash $R/tools/prof_pmc_mfma.sh ${tag}_cnnf32 $R/tools/cnn_probe.py --mode update --reps 6 --precision f32 2>&1 | grep "^k_cnn\|rc=" | cut -c1-330
+# r03: the trunk kernel (conv1 + conv2 + conv3 in one persistent kernel) at 4 pairs per workgroup: MFMA / wave-state and LDS counter passes
+bash $R/tools/prof_pmc_mfma.sh ${tag}_trunk $R/tools/cnn_probe.py --mode forward --precision bf16 --batch 2048 2>&1 | grep "^k_cnn_trunk\|rc=" | cut -c1-400
+bash $R/tools/prof_pmc_lds.sh ${tag}_trunk $R/tools/cnn_probe.py --mode forward --precision bf16 --batch 2048 2>&1 | grep "^k_cnn_trunk\|rc=" | cut -c1-400
 (bash $R/tools/kt_cnn.sh ${tag}_ub --mode update; bash $R/tools/kt_cnn.sh ${tag}_uf --mode update --precision f32; bash $R/tools/kt_cnn.sh ${tag}_fb --mode forward; bash $R/tools/kt_cnn.sh ${tag}_ff --mode forward --precision f32) > $out/cnn_$tag.txt 2>&1
 tail -3 $out/cnn_$tag.txt
 cd $R
@@ -26,9 +29,10 @@ python tools/per_sample_probe.py --json $out/probe_$tag.json 2>&1 | tail -8
 python tools/per_write_probe.py --json $out/wprobe_$tag.json 2>&1 | tail -22
 python tools/sweep.py --max-log2 18 --json $out/sweep_${tag}_f32.json 2>&1 | tail -3 | cut -c1-300
 python tools/sweep.py --max-log2 17 --no-actor --precision bf16 --json $out/sweep_${tag}_bf16.json 2>&1 | tail -2 | cut -c1-300
-python tools/cnn_sweep.py --json $out/cnn_sweep_$tag.json 2>&1 | tail -8 | cut -c1-260
+python tools/cnn_sweep.py --log2 9 11 13 --json $out/cnn_sweep_$tag.json 2>&1 | tail -8 | cut -c1-260
+python tools/cnn_sweep.py --log2 9 11 13 --precision bf16 --flags 4 --json $out/cnn_sweep_${tag}_layerwise.json 2>&1 | tail -4 | cut -c1-260
 # gpurun merges at most 64 MiB back: keep the summaries (json / txt / stats) and the one kernel trace collect_profiles.py reads, drop the raw counter dumps
 find $out -name "*counter_collection.csv" -delete 2>/dev/null
 find $out -name "*.db" -delete 2>/dev/null
-for d in $out/pmc_* $out/pmcs_* $out/pmcw_* $out/pmcm_* $out/kt_*; do [ -d "$d" ] && rm -rf "$d"; done
+for d in $out/pmc_* $out/pmcs_* $out/pmcw_* $out/pmcm_* $out/pmcl_* $out/kt_*; do [ -d "$d" ] && rm -rf "$d"; done
 du -sh $out | tail -1
