@@ -552,8 +552,9 @@ def cnn_lines(dq):
                                       "updates_per_sec": 1e6 / us, "env_steps_per_sec": 4 * Bc * 1e6 / us, "device_errors": ag.index.device_errors(),
                                       "note": "BASELINE configs[4] shape on ONE GPU, n-step 3 PER: 4 vector env steps of 512 synthetic frame-stack envs (CNN act + "
                                               "frame-ring add + PER index add) + 1 update from the ring (PER sample, gather, 3 forwards, backward, AdamW, priority write-back); "
-                                              "host-driven loop (no graph); r03: the synthetic env lives on the device (dqn_cnn_env_step_synth: forward 5 launches + 1 "
-                                              "policy / transition / ring kernel per vector step, + 1 index launch), ~60 launches per iteration"}
+                                              "host-driven loop (no graph); r03: the synthetic env lives on the device (dqn_cnn_env_step_synth: forward 3 launches -- the three "
+                                              "convolutions are one persistent kernel -- + 1 policy / transition / ring kernel per vector step, + 1 index launch: "
+                                              "dqn_per_index_step), 43 launches per iteration"}
     ag.close()
     return out
 
