@@ -1170,12 +1170,19 @@ static TrunkJob trunk_job(const dqn_cnn_handle *h, int which, const uint8_t *fra
     const float *P = h->params[which];
     const __bf16 *wp = (const __bf16 *)h->wp[which];
     return TrunkJob{frames, frames2 ? frames2 : frames, B1, B1 + B2, wp, wp + CNN_WP_OFF1, wp + CNN_WP_OFF2, P + h->L[0].o_b, P + h->L[1].o_b, P + h->L[2].o_b,
-                    want_maps ? (__bf16 *)act[0] : nullptr, want_maps ? (__bf16 *)act[1] : nullptr, (__bf16 *)act[2]};
+                    want_maps ? (__bf16 *)act[0] : nullptr, want_maps ? (__bf16 *)act[1] : nullptr, (__bf16 *)act[2], nullptr, 1, 0, 0};
 }
 // Agent._step's two passes in ONE trunk launch (bf16 mode): online over s | s' (maps kept for the backward), target over s'
-static bool cnn_trunk_both(dqn_cnn_handle *h, const uint8_t *s, const uint8_t *s2, int B, hipStream_t st) {
-    if (!h->bf16 || (h->flags & DQN_CNN_FLAG_LAYERWISE_CONV)) return false;
-    const TrunkJob on = trunk_job(h, DQN_NET_ONLINE, s, B, s2, B, h->act, true), tg = trunk_job(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->act_t, false);
+// ring_idx != nullptr: s / s2 are the frame ring's two arrays and transition b is row ring_idx[b] of s, row (ring_idx[b] + ring_off2)
+// mod capacity of s2 (dqn_cnn_update_replay: the last row of the n-step window)
+static bool cnn_trunk_fused(const dqn_cnn_handle *h) { return h->bf16 && !(h->flags & DQN_CNN_FLAG_LAYERWISE_CONV); }
+static bool cnn_trunk_both(dqn_cnn_handle *h, const uint8_t *s, const uint8_t *s2, int B, hipStream_t st, const int32_t *ring_idx = nullptr, int ring_off2 = 0) {
+    if (!cnn_trunk_fused(h)) return false;
+    TrunkJob on = trunk_job(h, DQN_NET_ONLINE, s, B, s2, B, h->act, true), tg = trunk_job(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->act_t, false);
+    if (ring_idx) {
+        on.idx = tg.idx = ring_idx; on.cap = tg.cap = h->ring_cap;
+        on.off1 = 0; on.off2 = ring_off2; tg.off1 = ring_off2; tg.off2 = 0;
+    }
     const int p0 = B, p1 = (B + 1) / 2, total = p0 + p1;
     const TrunkArgs ta{{on, tg}, p0, total};
     DQN_LAUNCH(k_cnn_trunk16, dim3((unsigned)(total < h->num_cus ? total : h->num_cus)), dim3(256), 0, st, ta);
@@ -1407,14 +1414,15 @@ extern "C" int dqn_cnn_allreduce_grads(dqn_cnn_handle *h, int32_t fc_leaf_done, 
 }
 
 static int cnn_update_impl(dqn_cnn_handle *h, const uint8_t *s, const int32_t *a, const float *r, const uint8_t *s2, const float *d,
-                           const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream) {
+                           const float *isw, float gamma, int32_t B, float *td_abs_out, float *loss_host, void *stream,
+                           const int32_t *ring_idx = nullptr, int ring_off2 = 0) {
     CNN_REQ(h && s && a && r && s2 && d, "null argument");
     CNN_REQ(B >= 1 && B <= h->max_batch, "B exceeds max_batch");
     hipStream_t st = (hipStream_t)stream;
     int rc = DQN_OK;
     // the target pass (:54) runs on the side stream in its own activation buffers, beside the online pass over s and s' (:52, :53)
     // (bf16 mode, r03: the convolutions of both passes are one launch; only the target's fc + heads go to the side stream)
-    const bool both = cnn_trunk_both(h, s, s2, B, st);
+    const bool both = ring_idx ? cnn_trunk_both(h, h->ring_s, h->ring_s2, B, st, ring_idx, ring_off2) : cnn_trunk_both(h, s, s2, B, st);
     if (h->side) { (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(h->side, h->ev_fork, 0); }
     cnn_forward_pair(h, DQN_NET_TARGET, s2, B, nullptr, 0, h->q[2], h->side ? h->side : st, h->act_t, false, both);
     if (h->side) (void)hipEventRecord(h->ev_tgt, h->side);
@@ -1591,8 +1599,21 @@ extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, cons
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(idx && B >= 1 && B <= h->max_batch, "bad argument");
     CNN_REQ(h->env_cur != h->stage_s2, "the synthetic envs' reset frames still sit in the staging buffer: take one dqn_cnn_env_step_synth before the first update");
-    int rc = dqn_cnn_replay_gather(h, idx, B, n_step, n_envs, gamma, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
     float gn = gamma;
     for (int k = 1; k < n_step; ++k) gn = gn * gamma;                  // gamma^n as n - 1 f32 products
+    if (cnn_trunk_fused(h)) {
+        // r03 (bf16 mode): the trunk kernel reads the sampled rows where they lie in the ring (its DMA source address). What is left
+        // of the gather -- action / n-step return / done, and the copy of s that conv1's weight gradient reads much later -- goes to
+        // the side stream, which the update joins before its backward anyway (14.4 MB instead of 2 x 14.4 MB, off the critical path)
+        CNN_REQ(n_step >= 1 && n_step <= 8 && (n_step == 1 || (n_envs >= 1 && h->ring_cap % n_envs == 0 && (long long)n_step * n_envs <= h->ring_cap)), "bad n_step / n_envs");
+        hipStream_t st = (hipStream_t)stream, sd = h->side ? h->side : st;
+        if (h->side) { (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(sd, h->ev_fork, 0); }
+        hipLaunchKernelGGL(k_cnn_gather, dim3(B, 1), dim3(256), 0, sd, h->ring_s, h->ring_s2, h->ring_a, h->ring_r, h->ring_d, idx, B, h->ring_cap,
+                           n_step, n_step == 1 ? 0 : n_envs, gamma, h->stage_s, h->stage_s2, h->stage_a, h->stage_r, h->stage_d);
+        CNN_TRY(hipGetLastError());
+        return cnn_update_impl(h, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, isw, gn, B, td_abs_out, loss_host, stream,
+                               idx, n_step == 1 ? 0 : (n_step - 1) * n_envs);
+    }
+    int rc = dqn_cnn_replay_gather(h, idx, B, n_step, n_envs, gamma, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, stream); if (rc) return rc;
     return cnn_update_impl(h, h->stage_s, h->stage_a, h->stage_r, h->stage_s2, h->stage_d, isw, gn, B, td_abs_out, loss_host, stream);
 }

@@ -37,6 +37,10 @@ struct TrunkJob {
     const __bf16 *w0, *w1, *w2;                        // fragment-packed shadows (CnnShadows::wp; conv1's holds W / 255)
     const float *b0, *b1, *b2;
     __bf16 *a0, *a1, *a2;                              // conv1 / conv2 maps: nullptr = not wanted; conv3's is always written
+    // idx != nullptr: f1 / f2 are rings of `cap` frame stacks and image b is the row (idx[b] + off1) mod cap of f1, image
+    // images1 + b the row (idx[b] + off2) mod cap of f2 -- the sampled transitions are read where they lie (the s / s' gather of
+    // Agent._step from the frame ring is this kernel's DMA source address: no 2 x 14.4 MB staging copy in front of the pass)
+    const int32_t *idx; long long cap; int off1, off2;
 };
 // One launch runs up to two passes (Agent._step: the online net over s | s' and the target net over s'): the pairs of pass 0,
 // then those of pass 1, form ONE list that the workgroups walk with stride gridDim -- every workgroup gets the same number of
@@ -115,7 +119,14 @@ k_cnn_trunk16(TrunkArgs ga) {
     //  per epilogue block, 4/5 of the kernel. The DMA's completion is waited for by hand: frames_landed.)
     auto dma = [&](const TrunkJob &g, int image) {
         image = image < g.B ? image : g.B - 1;
-        const uint8_t *p = image < g.images1 ? g.f1 + (long long)image * TR_FR : g.f2 + (long long)(image - g.images1) * TR_FR;
+        const bool second = image >= g.images1;
+        long long row = second ? image - g.images1 : image;
+        if (g.idx) {
+            row = g.idx[row];
+            row = row < 0 ? 0 : (row >= g.cap ? g.cap - 1 : row);
+            row = (row + (second ? g.off2 : g.off1)) % g.cap;
+        }
+        const uint8_t *p = (second ? g.f2 : g.f1) + row * TR_FR;
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int piece = wave + 4 * u, o = 1024 * piece + 16 * lane;
