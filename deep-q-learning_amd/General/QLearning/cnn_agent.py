@@ -44,7 +44,15 @@ class CnnVectorAgent:
         dev = self.cnn.device
         self.cnn.env_reset_synth(n_envs, seed)
         self.td_abs = torch.empty((self.B,), dtype=torch.float32, device=dev)
-        self._pos = torch.arange(n_envs, dtype=torch.int32, device=dev); self._zero_prio = torch.zeros((n_envs,), dtype=torch.float32, device=dev)
+        # r03: the index works on a stream of its own. Its launches (one per vector step, the draw, the write-back) depend on the CNN
+        # stream only through |delta| (write-back after the update) and feed it only idx / isw (update after the draw): they run
+        # beside the envs' forward passes instead of between them. Caller-held sample buffers: nothing is allocated across streams.
+        self.ist = self.index.stream
+        self.ist.wait_stream(torch.cuda.current_stream(dev))
+        self.ev_draw, self.ev_upd = torch.cuda.Event(), torch.cuda.Event()
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        self._bufs = (mk((self.B, 1), torch.float32), mk((self.B,), torch.int32), mk((self.B,), torch.float32), mk((self.B, 1), torch.float32),
+                      mk((self.B,), torch.uint8), mk((self.B,), torch.int32), mk((self.B,), torch.float32))
         self.env_steps = self.updates = 0
         self.losses = []
 
@@ -60,7 +68,8 @@ class CnnVectorAgent:
         first = self.cnn.env_step_synth(self.epsilon, self.p_done)
         assert first == (self.env_steps * n) % self.cnn.capacity, (first, self.env_steps)      # the two rings move in lockstep
         if self.n_step == 1:
-            self.index.per_index_advance(n)
+            with torch.cuda.stream(self.ist):
+                self.index.per_index_advance(n)
         else:
             # the frame ring holds one row per env step; the n-step transition that starts at a row exists once its n - 1
             # successors do. So the PER index learns of step t - n + 1 when step t arrives (its own ring counter is n - 1 steps
@@ -69,14 +78,23 @@ class CnnVectorAgent:
             zero_n = n if self.env_steps * n >= self.cnn.capacity else 0
             adv = n if self.env_steps >= self.n_step - 1 else 0
             if zero_n or adv:
-                self.index.per_index_step(adv, first, zero_n)
+                with torch.cuda.stream(self.ist):
+                    self.index.per_index_step(adv, first, zero_n)
         self.env_steps += 1
         self.epsilon = max(self.epsilon * self.decay, self.min_eps)
 
     def update(self, want_loss=False):
-        (_, _, _, _, _), idx, isw = self.index.per_sample(self.B, self.per_beta, self.seed, self.updates)
+        cur = torch.cuda.current_stream(self.cnn.device)
+        idx, isw = self._bufs[5], self._bufs[6]
+        with torch.cuda.stream(self.ist):
+            self.index.per_sample_into(self.B, self.per_beta, self.seed, self.updates, self._bufs)
+            self.ev_draw.record(self.ist)
+        cur.wait_event(self.ev_draw)
         loss = self.cnn.update_from_replay(idx, isw, self.gamma, td_abs_out=self.td_abs, want_loss=want_loss, n_step=self.n_step, n_envs=self.n_envs)
-        self.index.per_update_sorted(idx, self.td_abs)
+        self.ev_upd.record(cur)
+        with torch.cuda.stream(self.ist):
+            self.ist.wait_event(self.ev_upd)
+            self.index.per_update_sorted(idx, self.td_abs)
         self.updates += 1
         if self.updates % self.replace_frequency == 0:
             self.cnn.sync_target()                                          # q_agent.py:192-193
@@ -93,4 +111,5 @@ class CnnVectorAgent:
             for _ in range(self.train_frequency):
                 self.env_step()
             self.update(want_loss)
+        torch.cuda.current_stream(self.cnn.device).wait_stream(self.ist)     # (the last write-back: callers read the index after this)
         return self.losses
