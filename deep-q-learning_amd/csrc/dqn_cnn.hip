@@ -259,13 +259,9 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TI *__restrict__ in2, int im
 // dueling head (dddqn.py:29-31) on the fc features [B][512]: 16 rows per workgroup, thread (row, j) runs the k-ascending fmaf
 // chain of output j (0 = val, 1.. = adv) from LDS images of the rows and of the j-major head weights [16][512];
 // Q = val + adv - mean(adv) with the restatement's order of additions.
-// r03: with pol.ring_a set the kernel is also the vector env step's policy / reward / done row (the last third of k_cnn_synth_step):
-// the row's Q values are formed once more in registers (the same additions) and go through policy_row, so acting costs no launch
-// of its own behind the heads
-struct CnnPolicyArgs { int32_t *ring_a; float *ring_r, *ring_d; long long pos; unsigned long long seed, step; float epsilon, p_done; };
 template <typename TC>
 __global__ void __launch_bounds__(256)
-k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const float *__restrict__ bh, int A, int B, float *q, CnnPolicyArgs pol) {
+k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const float *__restrict__ bh, int A, int B, float *q) {
     constexpr int LS = CNN_F + 4;
     __shared__ __attribute__((aligned(16))) float lx[16 * LS];
     __shared__ __attribute__((aligned(16))) float lw[16 * LS];
@@ -301,15 +297,6 @@ k_cnn_head(const TC *__restrict__ feat, const float *__restrict__ wht, const flo
         for (int a = 1; a <= A; ++a) sum = sum + lo[16 * row + a];
         const float mean = __fdiv_rn(sum, (float)A);
         q[(long long)i * A + j] = (lo[16 * row] + lo[16 * row + 1 + j]) - mean;
-        if (pol.ring_a && j == 0) {
-            float qr[16];
-            for (int a = 0; a < A; ++a) qr[a] = (lo[16 * row] + lo[16 * row + 1 + a]) - mean;
-            const u32x4 o = philox_draw(pol.seed, pol.step, 0x80000000u + (uint32_t)i, DQN_STREAM_ENV);        // (piece indices stay below 2^31)
-            const u32x4 o2 = philox_draw(pol.seed, pol.step, 0xC0000000u + (uint32_t)i, DQN_STREAM_ENV);
-            pol.ring_r[pol.pos + i] = (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;     // Irwin-Hall normal (as ih_normal)
-            pol.ring_d[pol.pos + i] = u01(o2.x) < pol.p_done ? 1.0f : 0.0f;
-            pol.ring_a[pol.pos + i] = policy_row(qr, A, pol.epsilon, pol.seed, pol.step, i);                      // q_agent.py:137-141, as dqn_cnn_act
-        }
     }
 }
 
@@ -966,15 +953,9 @@ struct dqn_cnn_handle {
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
     int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
     int env_n = 0; uint64_t env_seed = 0; long long env_steps = 0; const uint8_t *env_cur = nullptr;   // dqn_cnn_env_*_synth
-    hipEvent_t ev_frames = nullptr; bool frames_pending = false;       // the vector step's frame copy / draw on the side stream (cnn_join_frames)
     void *comm = nullptr; int rank = 0, world = 1;     // dqn_cnn_comm_init: per-GPU learners, one gradient all-reduce per update
     hipStream_t comm_st = nullptr; hipEvent_t ev_fc = nullptr, ev_fc_done = nullptr;   // the fc leaf's all-reduce on a stream of its own (data-parallel update)
 };
-
-// every reader / writer of the frame ring on stream st first joins the vector step's frame kernel, if one is in flight on the side stream
-static void cnn_join_frames(dqn_cnn_handle *h, hipStream_t st) {
-    if (h->frames_pending && h->ev_frames) { (void)hipStreamWaitEvent(st, h->ev_frames, 0); h->frames_pending = false; }
-}
 
 struct LayerShape { int K, OC, positions; };            // host view of CnnGeo<l>: K = KH*KW*IC, output positions per frame stack
 template <int L> static LayerShape shape_of() { typedef CnnGeo<L> G; return LayerShape{G::KH * G::KW * G::IC, G::OC, G::OH * G::OW}; }
@@ -1077,7 +1058,6 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (h->side_kept) h->side = h->side_kept;
     dqn_rccl_comm_destroy(h->comm);
     if (h->ev_fc) (void)hipEventDestroy(h->ev_fc);
-    if (h->ev_frames) (void)hipEventDestroy(h->ev_frames);
     if (h->ev_fc_done) (void)hipEventDestroy(h->ev_fc_done);
     if (h->comm_st) (void)hipStreamDestroy(h->comm_st);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -1210,7 +1190,7 @@ static bool cnn_trunk_both(dqn_cnn_handle *h, const uint8_t *s, const uint8_t *s
 }
 // one pass over B1 frame stacks from `frames` followed by B2 from `frames2` (B2 = 0: a plain forward); q: [B1 + B2][A]
 template <typename TC>
-static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act, bool want_maps, bool trunk_done = false, const CnnPolicyArgs *pol = nullptr) {
+static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, int B1, const uint8_t *frames2, int B2, float *q, hipStream_t s, void *const *act, bool want_maps, bool trunk_done = false) {
     const float *P = h->params[which];
     const int B = B1 + B2;
     TC *a0 = (TC *)act[0], *a1 = (TC *)act[1], *a2 = (TC *)act[2], *a3 = (TC *)act[3];
@@ -1232,11 +1212,11 @@ static void cnn_forward_t(dqn_cnn_handle *h, int which, const uint8_t *frames, i
         launch_layer<TC, TC, 2>(s, B, a1, a1, B, (const TC *)h->wt[which][2], P + h->L[2].o_b, a2);
     }
     launch_layer<TC, TC, 3>(s, B, a2, a2, B, (const TC *)h->wt[which][3], P + h->L[3].o_b, a3, (h->flags & DQN_CNN_FLAG_FC_WIDE_TILE) != 0);
-    hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q, pol ? *pol : CnnPolicyArgs{});
+    hipLaunchKernelGGL((k_cnn_head<TC>), dim3((B + 15) / 16), dim3(256), 0, s, a3, h->wh[which], h->bh[which], h->A, B, q);
 }
-static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr, bool want_maps = true, bool trunk_done = false, const CnnPolicyArgs *pol = nullptr) {
+static void cnn_forward_pair(dqn_cnn_handle *h, int which, const uint8_t *f1, int B1, const uint8_t *f2, int B2, float *q, hipStream_t s, void *const *act = nullptr, bool want_maps = true, bool trunk_done = false) {
     if (!act) act = h->act;
-    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act, want_maps, trunk_done, pol); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act, want_maps, false, pol);
+    if (h->bf16) cnn_forward_t<__bf16>(h, which, f1, B1, f2, B2, q, s, act, want_maps, trunk_done); else cnn_forward_t<float>(h, which, f1, B1, f2, B2, q, s, act, want_maps);
 }
 
 /* Q[B][A] of the Nature-CNN dueling net for B stacks of four 84x84 u8 frames (NHWC). */
@@ -1511,7 +1491,6 @@ extern "C" int dqn_cnn_replay_add(dqn_cnn_handle *h, const uint8_t *s, const int
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(s && a && r && s2 && d && n >= 1 && n <= h->ring_cap, "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    cnn_join_frames(h, st);
     const long long pos = h->ring_counter % h->ring_cap, n1 = (pos + n <= h->ring_cap) ? n : h->ring_cap - pos, n2 = n - n1;
     auto put = [&](void *ring, const void *src, size_t row) -> hipError_t {
         hipError_t e = hipMemcpyAsync((char *)ring + pos * row, src, n1 * row, hipMemcpyDeviceToDevice, st);
@@ -1545,7 +1524,7 @@ k_cnn_synth_step(const uint8_t *__restrict__ cur, uint8_t *__restrict__ ring_s, 
         d2[p] = uint4{o.x, o.y, o.z, o.w};
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q && i < n) {                                  // (q == nullptr: the heads kernel files action / reward / done -- CnnPolicyArgs)
+    if (i < n) {
         const u32x4 o = philox_draw(seed, step, 0x80000000u + (uint32_t)i, DQN_STREAM_ENV);        // (piece indices stay below 2^31)
         const u32x4 o2 = philox_draw(seed, step, 0xC0000000u + (uint32_t)i, DQN_STREAM_ENV);
         ring_r[pos + i] = (((u01(o.x) + u01(o.y)) + (u01(o.z) + u01(o.w))) - 2.0f) * 1.73205078f;     // Irwin-Hall normal (as ih_normal)
@@ -1567,7 +1546,6 @@ k_cnn_synth_frames(uint8_t *__restrict__ dst, int n, unsigned long long seed, un
 extern "C" int dqn_cnn_env_reset_synth(dqn_cnn_handle *h, int32_t n, uint64_t seed, void *stream) {
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(n >= 1 && n <= h->max_batch && h->ring_cap % n == 0, "dqn_cnn_env_reset_synth: n must divide the ring capacity and fit max_batch");
-    cnn_join_frames(h, (hipStream_t)stream);
     h->env_n = n; h->env_seed = seed; h->env_steps = 0;
     h->env_cur = h->stage_s2;                                           // (free until the first update stages a batch: by then the envs live in the ring)
     hipLaunchKernelGGL(k_cnn_synth_frames, dim3(1024), dim3(256), 0, (hipStream_t)stream, h->stage_s2, n, seed, 0x8000000000000000ull);
@@ -1584,27 +1562,9 @@ extern "C" int dqn_cnn_env_step_synth(dqn_cnn_handle *h, float epsilon, float p_
     hipStream_t st = (hipStream_t)stream;
     const int n = h->env_n;
     const long long pos = h->ring_counter % h->ring_cap;
-    // r03: the frame part of the step (copy of the current stacks into the ring's s rows, the next stacks drawn into its s' rows) does
-    // not depend on the forward pass: it runs on the side stream beside it -- after everything issued before this step (an update
-    // may still be reading the rows it overwrites), and every later reader of the ring joins it (cnn_join_frames). The policy /
-    // reward / done row is the heads kernel's epilogue. Not when the ring holds a single vector step (the envs' current stacks
-    // would be overwritten in place under the forward pass).
-    cnn_join_frames(h, st);
-    const bool beside = h->side != nullptr && h->ring_cap >= 2ll * n;
-    if (beside && !h->ev_frames && hipEventCreateWithFlags(&h->ev_frames, hipEventDisableTiming) != hipSuccess) h->ev_frames = nullptr;
-    if (beside && h->ev_frames) {
-        (void)hipEventRecord(h->ev_fork, st); (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-        hipLaunchKernelGGL(k_cnn_synth_step, dim3(2048), dim3(256), 0, h->side, h->env_cur, h->ring_s, h->ring_s2, h->ring_r, h->ring_d, pos, n,
-                           h->env_seed, (unsigned long long)h->env_steps, p_done, (const float *)nullptr, h->A, epsilon, h->ring_a);
-        (void)hipEventRecord(h->ev_frames, h->side);
-        h->frames_pending = true;
-        const CnnPolicyArgs pol{h->ring_a, h->ring_r, h->ring_d, pos, h->env_seed, (unsigned long long)h->env_steps, epsilon, p_done};
-        cnn_forward_pair(h, DQN_NET_ONLINE, h->env_cur, n, nullptr, 0, h->q[0], st, nullptr, false, false, &pol);
-    } else {
-        cnn_forward_pair(h, DQN_NET_ONLINE, h->env_cur, n, nullptr, 0, h->q[0], st, nullptr, false);
-        hipLaunchKernelGGL(k_cnn_synth_step, dim3(2048), dim3(256), 0, st, h->env_cur, h->ring_s, h->ring_s2, h->ring_r, h->ring_d, pos, n,
-                           h->env_seed, (unsigned long long)h->env_steps, p_done, h->q[0], h->A, epsilon, h->ring_a);
-    }
+    cnn_forward_pair(h, DQN_NET_ONLINE, h->env_cur, n, nullptr, 0, h->q[0], (hipStream_t)stream, nullptr, false);
+    hipLaunchKernelGGL(k_cnn_synth_step, dim3(2048), dim3(256), 0, st, h->env_cur, h->ring_s, h->ring_s2, h->ring_r, h->ring_d, pos, n,
+                       h->env_seed, (unsigned long long)h->env_steps, p_done, h->q[0], h->A, epsilon, h->ring_a);
     CNN_TRY(hipGetLastError());
     h->env_cur = h->ring_s2 + pos * CNN_FRAME_BYTES;
     if (first_index) *first_index = pos;
@@ -1625,7 +1585,6 @@ extern "C" int dqn_cnn_replay_gather(dqn_cnn_handle *h, const int32_t *idx, int3
     CNN_REQ(h && h->ring_arena, "no ring: call dqn_cnn_replay_init");
     CNN_REQ(idx && s && a && r && s2 && d && B >= 1, "bad argument");
     CNN_REQ(n_step >= 1 && n_step <= 8 && (n_step == 1 || (n_envs >= 1 && h->ring_cap % n_envs == 0 && (long long)n_step * n_envs <= h->ring_cap)), "bad n_step / n_envs");
-    cnn_join_frames(h, (hipStream_t)stream);
     hipLaunchKernelGGL(k_cnn_gather, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, h->ring_s, h->ring_s2, h->ring_a, h->ring_r, h->ring_d, idx, B, h->ring_cap,
                        n_step, n_step == 1 ? 0 : n_envs, gamma, s, s2, a, r, d);
     CNN_TRY(hipGetLastError());
@@ -1642,7 +1601,6 @@ extern "C" int dqn_cnn_update_replay(dqn_cnn_handle *h, const int32_t *idx, cons
     CNN_REQ(h->env_cur != h->stage_s2, "the synthetic envs' reset frames still sit in the staging buffer: take one dqn_cnn_env_step_synth before the first update");
     float gn = gamma;
     for (int k = 1; k < n_step; ++k) gn = gn * gamma;                  // gamma^n as n - 1 f32 products
-    cnn_join_frames(h, (hipStream_t)stream);
     if (cnn_trunk_fused(h)) {
         // r03 (bf16 mode): the trunk kernel reads the sampled rows where they lie in the ring (its DMA source address). What is left
         // of the gather -- action / n-step return / done, and the copy of s that conv1's weight gradient reads much later -- goes to
