@@ -25,9 +25,12 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--plain", type=int, default=0)
     ap.add_argument("--lib", default=None, help="a variant build of the library (other PS_* macros)")
+    ap.add_argument("--log2n", type=int, default=None, help="ring capacity 2^n instead of the bench's 2^20 (2^24: ring 1 GB + tree 128 MB, beyond the 256 MB Infinity Cache)")
     args = ap.parse_args()
     if args.lib:
         dq._lib.LIB_PATH = os.path.abspath(args.lib)
+    if args.log2n:
+        bench.LOG2N = args.log2n                     # (prefill and the byte formula read it)
     D, L = bench.D, bench.LOG2N
     maxB = 1 << max(args.log2)
     eng = dq.Engine(dq.EngineConfig(obs_dim=D, hidden1=16, hidden2=16, num_actions=bench.A, capacity=1 << L, use_per=True,
