@@ -255,6 +255,7 @@ k_cnn_layer(int M, const TI *__restrict__ in, const TI *__restrict__ in2, int im
 }
 
 #include "dqn_cnn_trunk.h"
+#include "dqn_cnn_btrunk.h"
 
 // dueling head (dddqn.py:29-31) on the fc features [B][512]: 16 rows per workgroup, thread (row, j) runs the k-ascending fmaf
 // chain of output j (0 = val, 1.. = adv) from LDS images of the rows and of the j-major head weights [16][512];
@@ -781,12 +782,14 @@ k_cnn_reduce(CnnSegs segs, long long total_units, float *__restrict__ grad, cons
 // backward-data (BwdGeo), output-major heads
 struct CnnOffs { long long o_w[4], o_b[4], o_wv, o_bv, o_wa, o_ba, P; int A; };
 template <typename TC>
-struct CnnShadows { TC *wt[4]; TC *wb[4]; float *wh, *bh; TC *wp; };
+struct CnnShadows { TC *wt[4]; TC *wb[4]; float *wh, *bh; TC *wp, *wpb; };
 // wp (bf16 mode): the three convolutions' weights once more, packed by MFMA fragment for k_cnn_trunk16 -- element (n, k) of layer l at
 // CNN_WP_OFF[l] + ((((n >> 5) * (K / 16) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7): the 64 lanes' 16-byte fragments of
 // (column tile, k-step) are 1 KB contiguous (as [N][K] they are 64 pieces of 64 different cache lines: the trunk kernel's 84
 // fragment loads per lane took longer than its three convolutions)
 constexpr int CNN_WP_OFF1 = 32 * 256, CNN_WP_OFF2 = CNN_WP_OFF1 + 64 * 512, CNN_WP_ELEMS = CNN_WP_OFF2 + 64 * 576;
+// wpb: the backward-data matrices of conv3 ([64 ic][576]) and conv2 ([4 classes][32 ic][256]) packed the same way for k_cnn_btrunk16
+constexpr int CNN_WPB_OFF1 = 64 * 576, CNN_WPB_ELEMS = CNN_WPB_OFF1 + 4 * 32 * 256;
 template <typename TC>
 __device__ __forceinline__ void scatter_shadows(const CnnOffs &o, const CnnShadows<TC> &sh, long long i, float v) {
     if (i >= o.o_wv) {
@@ -808,10 +811,15 @@ __device__ __forceinline__ void scatter_shadows(const CnnOffs &o, const CnnShado
     if (sizeof(TC) == 2 && l < 3)
         sh.wp[(l == 0 ? 0 : (l == 1 ? CNN_WP_OFF1 : CNN_WP_OFF2)) + ((((n >> 5) * (K >> 4) + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 3) + (k & 7)] = (TC)vf;
     if (l == 3) sh.wb[3][e] = (TC)v;
-    else if (l == 2) { const int tap = k >> 6, ic = k & 63; sh.wb[2][(long long)ic * 576 + tap * 64 + n] = (TC)v; }
+    else if (l == 2) {
+        const int tap = k >> 6, ic = k & 63, kk = tap * 64 + n;       // row ic, column kk of conv3^T
+        sh.wb[2][(long long)ic * 576 + kk] = (TC)v;
+        if (sizeof(TC) == 2) sh.wpb[((((ic >> 5) * 36 + (kk >> 4)) * 64 + ((kk >> 3) & 1) * 32 + (ic & 31)) << 3) + (kk & 7)] = (TC)v;
+    }
     else if (l == 1) {
         const int tap = k >> 5, ic = k & 31, kh = tap >> 2, kw = tap & 3, cl = (kh & 1) * 2 + (kw & 1), tt = (kh >> 1) * 2 + (kw >> 1);
         sh.wb[1][((long long)cl * 32 + ic) * 256 + tt * 64 + n] = (TC)v;
+        if (sizeof(TC) == 2) { const int kk = tt * 64 + n; sh.wpb[CNN_WPB_OFF1 + (((cl * 16 + (kk >> 4)) * 64 + ((kk >> 3) & 1) * 32 + ic) << 3) + (kk & 7)] = (TC)v; }
     }
 }
 template <typename TC>
@@ -936,6 +944,7 @@ struct dqn_cnn_handle {
     void *wt[2][4] = {{nullptr}};                      // forward shadows [N][K] of the four GEMM layers
     void *wb[2][4] = {{nullptr}};                      // backward-data shadows (BwdGeo; [1..3])
     void *wp[2] = {nullptr, nullptr};                  // bf16 mode: conv weights packed by MFMA fragment (k_cnn_trunk16)
+    void *wpb[2] = {nullptr, nullptr};                 // ... and the backward-data matrices of conv3 / conv2 (k_cnn_btrunk16)
     float *wh[2] = {nullptr, nullptr}, *bh[2] = {nullptr, nullptr};   // heads, output-major [16][512] (0 = val, 1.. = adv), biases [1 + A]
     void *act[4] = {nullptr};                          // layer outputs (kept for the backward)
     void *act_t[4] = {nullptr};                        // the target pass of dqn_cnn_update (runs beside the online pass)
@@ -952,6 +961,7 @@ struct dqn_cnn_handle {
     hipStream_t side = nullptr; hipEvent_t ev_dz[4] = {nullptr}, ev_side = nullptr, ev_fork = nullptr, ev_tgt = nullptr;    // the dW kernels of layers 1..3 run beside the backward-data chain
     int adamw = 1; float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
     int flags = 0; hipStream_t side_kept = nullptr;    // dqn_cnn_set_flags (diagnostics)
+    hipStream_t side2 = nullptr; hipEvent_t ev_side2 = nullptr;        // r03: conv3's / conv2's dW on a second side stream (beside the fc leaf's step on the first)
     int env_n = 0; uint64_t env_seed = 0; long long env_steps = 0; const uint8_t *env_cur = nullptr;   // dqn_cnn_env_*_synth
     void *comm = nullptr; int rank = 0, world = 1;     // dqn_cnn_comm_init: per-GPU learners, one gradient all-reduce per update
     hipStream_t comm_st = nullptr; hipEvent_t ev_fc = nullptr, ev_fc_done = nullptr;   // the fc leaf's all-reduce on a stream of its own (data-parallel update)
@@ -989,7 +999,7 @@ static CnnOffs cnn_offs(const dqn_cnn_handle *h) {
 template <typename TC> static CnnShadows<TC> cnn_shadows(const dqn_cnn_handle *h, int which) {
     CnnShadows<TC> s{};
     for (int l = 0; l < 4; ++l) { s.wt[l] = (TC *)h->wt[which][l]; s.wb[l] = (TC *)h->wb[which][l]; }
-    s.wh = h->wh[which]; s.bh = h->bh[which]; s.wp = (TC *)h->wp[which];
+    s.wh = h->wh[which]; s.bh = h->bh[which]; s.wp = (TC *)h->wp[which]; s.wpb = (TC *)h->wpb[which];
     return s;
 }
 
@@ -1020,7 +1030,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
         sz_slab[l] = al((size_t)h->smax[l] * h->L[l].K * h->L[l].N * 4); sz_bslab[l] = al((size_t)h->smax[l] * h->L[l].N * 4);
     }
     const size_t hblocks = ((size_t)max_batch + 15) / 16, sz_hslab = al(hblocks * 16 * CNN_F * 4), sz_hbslab = al(hblocks * 16 * 4);
-    const size_t sz_wp = al((size_t)CNN_WP_ELEMS * 2);
+    const size_t sz_wp = al((size_t)CNN_WP_ELEMS * 2) + al((size_t)CNN_WPB_ELEMS * 2);
     size_t total = 5 * sz_params + 4 * (sz_wt[0] + sz_wt[1] + sz_wt[2] + sz_wt[3]) + 2 * (sz_wh + sz_bh + sz_wp) + 6 * sz_q + 4 * al((size_t)max_batch * 4) + 1024 + sz_hslab + sz_hbslab;
     for (int l = 0; l < 4; ++l) total += 4 * sz_act[l] + sz_slab[l] + sz_bslab[l];
     hipError_t e = hipMalloc(&h->arena, total);
@@ -1030,7 +1040,7 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
     for (int w = 0; w < 2; ++w) {
         h->params[w] = (float *)take(sz_params);
         for (int l = 0; l < 4; ++l) { h->wt[w][l] = take(sz_wt[l]); h->wb[w][l] = take(sz_wt[l]); }
-        h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh); h->wp[w] = take(sz_wp);
+        h->wh[w] = (float *)take(sz_wh); h->bh[w] = (float *)take(sz_bh); h->wp[w] = take(sz_wp); h->wpb[w] = (char *)h->wp[w] + al((size_t)CNN_WP_ELEMS * 2);
     }
     h->grad = (float *)take(sz_params); h->mu = (float *)take(sz_params); h->nu = (float *)take(sz_params);
     for (int l = 0; l < 4; ++l) { h->act[l] = take(2 * sz_act[l]); h->act_t[l] = take(sz_act[l]); h->dz[l] = take(sz_act[l]); h->slab[l] = (float *)take(sz_slab[l]); h->bslab[l] = (float *)take(sz_bslab[l]); }
@@ -1045,6 +1055,10 @@ extern "C" int dqn_cnn_create(int32_t num_actions, int32_t max_batch, int32_t pr
                   && hipEventCreateWithFlags(&h->ev_tgt, hipEventDisableTiming) == hipSuccess;
         for (int l = 1; l < 4; ++l) ok = ok && hipEventCreateWithFlags(&h->ev_dz[l], hipEventDisableTiming) == hipSuccess;
         if (!ok) { (void)hipStreamDestroy(h->side); h->side = nullptr; }
+        else if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_side2, hipEventDisableTiming) != hipSuccess) {
+            if (h->side2) (void)hipStreamDestroy(h->side2);
+            h->side2 = nullptr;
+        }
     } else h->side = nullptr;
     const CnnOptState st0{1.0, 1.0, 0, 3e-4f};
     (void)hipMemcpy(h->opt, &st0, sizeof(st0), hipMemcpyHostToDevice);
@@ -1061,6 +1075,8 @@ extern "C" int dqn_cnn_destroy(dqn_cnn_handle *h) {
     if (h->ev_fc_done) (void)hipEventDestroy(h->ev_fc_done);
     if (h->comm_st) (void)hipStreamDestroy(h->comm_st);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->ev_side2) (void)hipEventDestroy(h->ev_side2);
     for (int l = 1; l < 4; ++l) if (h->ev_dz[l]) (void)hipEventDestroy(h->ev_dz[l]);
     if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1284,7 +1300,10 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     if (prep_opt) hipLaunchKernelGGL(k_cnn_opt_prep, dim3(1), dim3(1), 0, sd, h->opt, h->b1, h->b2);
     launch_dw<TC, TC, 3>(h, sd, B, (const TC *)h->act[2], (const TC *)h->dz[3], segs, nseg, 1.0f);
     launch_bwd_data<TC, 3>(h, s, B);
-    if (h->side) { (void)hipEventRecord(h->ev_dz[2], s); (void)hipStreamWaitEvent(sd, h->ev_dz[2], 0); }
+    // (r03: conv3's and conv2's dW on a SECOND side stream: behind the fc leaf's 20 us optimizer step on the first they were the
+    //  update's critical path -- dW3 + leaf step + dW2 + dW1 = 80 us in a row against 60 on the caller's stream)
+    hipStream_t sd2 = (h->side && h->side2 && cnn_trunk_fused(h)) ? h->side2 : sd;      // (exact-f32 mode: its dW kernels fill the chip, measured slower)
+    if (h->side) { (void)hipEventRecord(h->ev_dz[2], s); (void)hipStreamWaitEvent(sd, h->ev_dz[2], 0); if (sd2 != sd) (void)hipStreamWaitEvent(sd2, h->ev_dz[2], 0); }
     // the fc leaf (95 % of the parameters) is complete when its single-slice dW is (written straight into the gradient) and
     // backward-data has read the fc weights for the last time: its Adam step goes here, beside the rest of the backward
     bool fc_done = false;
@@ -1304,13 +1323,28 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
             (void)hipEventRecord(h->ev_fc_done, h->comm_st);
         }
     }
-    launch_dw<TC, TC, 2>(h, sd, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
-    launch_bwd_data<TC, 2>(h, s, B);
-    if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd, h->ev_dz[1], 0); }
-    launch_dw<TC, TC, 1>(h, sd, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
-    launch_bwd_data<TC, 1>(h, s, B);
+    launch_dw<TC, TC, 2>(h, sd2, B, (const TC *)h->act[1], (const TC *)h->dz[2], segs, nseg, 1.0f);
+    bool bfused = false;
+    if constexpr (sizeof(TC) == 2) {
+        if (cnn_trunk_fused(h)) {                      // r03: conv3^T and conv2^T in one persistent kernel (dqn_cnn_btrunk.h)
+            const BTrunkArgs ba{(const __bf16 *)h->dz[2], (const __bf16 *)h->act[1], (const __bf16 *)h->act[0], (__bf16 *)h->dz[1], (__bf16 *)h->dz[0],
+                                (const __bf16 *)h->wpb[0], (const __bf16 *)h->wpb[0] + CNN_WPB_OFF1, B};
+            const int npairs = (B + 1) / 2;
+            DQN_LAUNCH(k_cnn_btrunk16, dim3((unsigned)(npairs < h->num_cus ? npairs : h->num_cus)), dim3(256), 0, s, ba);
+            if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd2, h->ev_dz[1], 0); }
+            launch_dw<TC, TC, 1>(h, sd2, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
+            bfused = true;
+        }
+    }
+    if (!bfused) {
+        launch_bwd_data<TC, 2>(h, s, B);
+        if (h->side) { (void)hipEventRecord(h->ev_dz[1], s); (void)hipStreamWaitEvent(sd2, h->ev_dz[1], 0); }
+        launch_dw<TC, TC, 1>(h, sd2, B, (const TC *)h->act[0], (const TC *)h->dz[1], segs, nseg, 1.0f);
+        launch_bwd_data<TC, 1>(h, s, B);
+    }
     launch_dw<uint8_t, TC, 0>(h, s, B, frames, (const TC *)h->dz[0], segs, nseg, 255.0f);      // the kernel multiplies integer pixels (both modes)
     if (h->side) { (void)hipEventRecord(h->ev_side, sd); (void)hipStreamWaitEvent(s, h->ev_side, 0); }
+    if (sd2 != sd) { (void)hipEventRecord(h->ev_side2, sd2); (void)hipStreamWaitEvent(s, h->ev_side2, 0); }
     long long total = 0;
     for (int i = 0; i < nseg; ++i) total += segs.s[i].units;
     segs.count = nseg;
