@@ -80,20 +80,28 @@ k_cnn_btrunk16(BTrunkArgs g) {
             int m = 32 * wm + c, img = m >= 81 ? 1 : 0, pos = m - 81 * img, iy = pos / 9, ix = pos - 9 * iy;
             const unsigned char *ab = lds + BT_OFF_Z3 + img * BT_IMG + ((iy + 2) * 11 + ix + 2) * BT_PIX + 16 * h;
             trunk_fill(ring, ab, off3);
+            // the ReLU gates of a tile are asked for ONE TILE AHEAD (a global round trip is longer than a tile's MFMAs)
+            auto gates3 = [&](int gimg, int gpos, bf16x4t (&gt)[4]) {
+                int ig = 2 * pair + gimg; ig = ig < g.B ? ig : g.B - 1;
+                const __bf16 *gp = g.a1 + ((long long)ig * 81 + gpos) * 64 + 32 * wn + 4 * h;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) gt[gq] = *reinterpret_cast<const bf16x4t *>(gp + 8 * gq);
+            };
+            bf16x4t gate[4], gate_next[4];
+            gates3(img, pos, gate_next);
             for (int t = wm; t < 6; t += 2) {
                 const int cimg = img, cpos = pos, ciy = iy, cix = ix, imgG = 2 * pair + cimg;
                 const bool valid = 32 * t + c < 162 && imgG < g.B;
-                bf16x4t gate[4];
-                {
-                    const __bf16 *gp = g.a1 + ((long long)(imgG < g.B ? imgG : g.B - 1) * 81 + cpos) * 64 + 32 * wn + 4 * h;
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) gate[gq] = *reinterpret_cast<const bf16x4t *>(gp + 8 * gq);
+                for (int gq = 0; gq < 4; ++gq) gate[gq] = gate_next[gq];
+                if (t + 2 < 6) {
+                    m = 32 * (t + 2) + c; m = m < 162 ? m : 161;
+                    img = m >= 81 ? 1 : 0; pos = m - 81 * img; iy = pos / 9; ix = pos - 9 * iy;
+                    gates3(img, pos, gate_next);
                 }
                 f32x16c acc;
                 trunk_tile<36>(w3r, ring, ab, off3, acc);
                 if (t + 2 < 6) {
-                    m = 32 * (t + 2) + c; m = m < 162 ? m : 161;
-                    img = m >= 81 ? 1 : 0; pos = m - 81 * img; iy = pos / 9; ix = pos - 9 * iy;
                     ab = lds + BT_OFF_Z3 + img * BT_IMG + ((iy + 2) * 11 + ix + 2) * BT_PIX + 16 * h;
                     trunk_fill(ring, ab, off3);
                 }
@@ -122,21 +130,32 @@ k_cnn_btrunk16(BTrunkArgs g) {
             int m = c, img = 0, pos = m, i2 = pos / 10, j2 = pos - 10 * i2;
             const unsigned char *ab = lds + BT_OFF_Z2 + img * BT_IMG + ((i2 + 1) * 11 + j2 + 1) * BT_PIX + 16 * h;
             trunk_fill(ring, ab, off2);
-            for (int t = 0; t < 7; ++t) {
-                const int cimg = img, ci2 = i2, cj2 = j2, imgG = 2 * pair + cimg;
-                const bool valid = 32 * t + c < 200 && imgG < g.B;
-                const long long opix = ((long long)(imgG < g.B ? imgG : g.B - 1) * 20 + 2 * ci2 + ph) * 20 + 2 * cj2 + pw;
-                bf16x4t gate[4];
-                {
-                    const __bf16 *gp = g.a0 + opix * 32 + 4 * h;
+            auto opix_of = [&](int gimg, int gi2, int gj2) {
+                int ig = 2 * pair + gimg; ig = ig < g.B ? ig : g.B - 1;
+                return ((long long)ig * 20 + 2 * gi2 + ph) * 20 + 2 * gj2 + pw; };
+            auto gates2 = [&](long long px, bf16x4t (&gt)[4]) {
+                const __bf16 *gp = g.a0 + px * 32 + 4 * h;
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) gate[gq] = *reinterpret_cast<const bf16x4t *>(gp + 8 * gq);
+                for (int gq = 0; gq < 4; ++gq) gt[gq] = *reinterpret_cast<const bf16x4t *>(gp + 8 * gq);
+            };
+            bf16x4t gate[4], gate_next[4];
+            long long opix_next = opix_of(img, i2, j2);
+            gates2(opix_next, gate_next);
+            for (int t = 0; t < 7; ++t) {
+                const int cimg = img, imgG = 2 * pair + cimg;
+                const bool valid = 32 * t + c < 200 && imgG < g.B;
+                const long long opix = opix_next;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) gate[gq] = gate_next[gq];
+                if (t + 1 < 7) {
+                    m = 32 * (t + 1) + c; m = m < 200 ? m : 199;
+                    img = m >= 100 ? 1 : 0; pos = m - 100 * img; i2 = pos / 10; j2 = pos - 10 * i2;
+                    opix_next = opix_of(img, i2, j2);
+                    gates2(opix_next, gate_next);
                 }
                 f32x16c acc;
                 trunk_tile<16>(w2r, ring, ab, off2, acc);
                 if (t + 1 < 7) {
-                    m = 32 * (t + 1) + c; m = m < 200 ? m : 199;
-                    img = m >= 100 ? 1 : 0; pos = m - 100 * img; i2 = pos / 10; j2 = pos - 10 * i2;
                     ab = lds + BT_OFF_Z2 + img * BT_IMG + ((i2 + 1) * 11 + j2 + 1) * BT_PIX + 16 * h;
                     trunk_fill(ring, ab, off2);
                 }
