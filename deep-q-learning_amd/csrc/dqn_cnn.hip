@@ -1302,7 +1302,10 @@ static bool cnn_backward_t(dqn_cnn_handle *h, const uint8_t *frames, const float
     launch_bwd_data<TC, 3>(h, s, B);
     // (r03: conv3's and conv2's dW on a SECOND side stream: behind the fc leaf's 20 us optimizer step on the first they were the
     //  update's critical path -- dW3 + leaf step + dW2 + dW1 = 80 us in a row against 60 on the caller's stream)
-    hipStream_t sd2 = (h->side && h->side2 && cnn_trunk_fused(h)) ? h->side2 : sd;      // (exact-f32 mode: its dW kernels fill the chip, measured slower)
+#ifndef CNN_SD2_MAX_B
+#define CNN_SD2_MAX_B 1024
+#endif
+    hipStream_t sd2 = (h->side && h->side2 && cnn_trunk_fused(h) && B <= CNN_SD2_MAX_B) ? h->side2 : sd;      // (exact-f32 mode, large batches: the dW kernels fill the chip, measured slower)
     if (h->side) { (void)hipEventRecord(h->ev_dz[2], s); (void)hipStreamWaitEvent(sd, h->ev_dz[2], 0); if (sd2 != sd) (void)hipStreamWaitEvent(sd2, h->ev_dz[2], 0); }
     // the fc leaf (95 % of the parameters) is complete when its single-slice dW is (written straight into the gradient) and
     // backward-data has read the fc weights for the last time: its Adam step goes here, beside the rest of the backward
