@@ -268,6 +268,7 @@ k_cnn_trunk16(TrunkArgs ga) {
             for (int t = wm; t < 6; t += 2) {
                 f32x16c acc;
                 trunk_tile<32>(w1r, ring, ab, off1, acc);
+                TSTAMP(11 + 2 * (t >> 1));                 // (diagnostic builds: conv2's tiles -- MFMA loop | epilogue)
                 const int cimg = img, cpos = pos, coy = oy, cox = ox;
                 const bool valid = 32 * t + c < 162;
                 if (t + 2 < 6) {
@@ -289,6 +290,7 @@ k_cnn_trunk16(TrunkArgs ga) {
                         for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<bf16x4t *>(gd + 8 * gq) = o[gq];
                     }
                 }
+                TSTAMP(12 + 2 * (t >> 1));
             }
         }
         TSTAMP(8);

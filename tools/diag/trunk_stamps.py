@@ -22,7 +22,7 @@ print("forward wall us (trunk + fc + heads):", round(e0.elapsed_time(e1) * 1e3 /
 buf = (C.c_ulonglong * (8 * 64 * 2))()
 assert e.lib.dqn_debug_stamps(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(8, 64, 2).astype(np.int64)[7]
-names = {0: "kernel start", 1: "loop top (weights requested)", 2: "image 0 landed + barrier", 3: "convert 0 + barrier + dma 1", 4: "conv1 image 0 (wave 0: 4 tiles)", 5: "image 1 landed, convert, barrier, dma next", 6: "conv1 image 1", 7: "barrier", 8: "conv2 (3 tiles)", 9: "barrier", 10: "conv3 (2 tiles)", 20: "[block 0 start, same launch]", 30: "[block 0 conv3 end]"}
+names = {0: "kernel start", 1: "loop top (weights requested)", 2: "image 0 landed + barrier", 3: "convert 0 + barrier + dma 1", 4: "conv1 image 0 (wave 0: 4 tiles)", 5: "image 1 landed, convert, barrier, dma next", 6: "conv1 image 1", 7: "barrier", 8: "conv2 (3 tiles)", 9: "barrier", 10: "conv3 (2 tiles)", 11: "  conv2 tile 0 MFMA loop", 12: "  conv2 tile 0 next fill + epilogue", 13: "  conv2 tile 1 MFMA loop", 14: "  conv2 tile 1 epilogue", 15: "  conv2 tile 2 MFMA loop", 16: "  conv2 tile 2 epilogue", 20: "[block 0 start, same launch]", 30: "[block 0 conv3 end]"}
 order = sorted((int(t[k, 1]), k) for k in names if t[k, 0])
 prev = order[0][0]
 for cyc, k in order:
