@@ -19,7 +19,10 @@ import deep_q_learning_amd as dq  # noqa: E402
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=40.0)
     ap.add_argument("--cfg3", action="store_true", help="BASELINE configs[2] (CartPole, 4096 envs, 2x64, B = 8192) instead of the bench shape")
+    ap.add_argument("--cnn", action="store_true", help="the configs[4] loop (CnnVectorAgent: 512 synthetic frame-stack envs, n-step 3, PER index on its own stream) instead")
     args = ap.parse_args()
+    if args.cnn:
+        return soak_cnn(args.seconds)
     if args.cfg3:
         bench.D, bench.H1, bench.H2, bench.A, bench.B, bench.N_ENVS = 4, 64, 64, 2, 8192, 4096
     for prec in ("f32", "bf16"):
@@ -52,6 +55,35 @@ def main():
         print(f"{prec}: {iters} iterations in {time.time() - t0:.1f} s ({iters / (time.time() - t0):.0f}/s incl. checks), loss {loss:.4f}, "
               f"{checks} tree checks ok", flush=True)
         e.close()
+
+
+def soak_cnn(seconds):
+    """the loop of BASELINE configs[4]'s shape: tens of thousands of host-driven iterations across the three streams (CNN, its side
+    streams, the index stream); along the way: finite loss and parameters, no device error, the index's sum-tree invariant, both rings
+    in lockstep"""
+    from deep_q_learning_amd.General.QLearning.cnn_agent import CnnVectorAgent
+    ag = CnnVectorAgent(n_envs=512, num_actions=6, capacity=1 << 14, batch_size=512, precision="bf16", train_frequency=4, seed=5, n_step=3)
+    ag.init_params(torch.randn(ag.cnn.param_count) * 0.02)
+    N = 1 << 14
+    k = torch.arange(1, N, device=ag.cnn.device)
+    t0 = time.time(); iters = 0; checks = 0
+    while time.time() - t0 < seconds:
+        ag.training(500)
+        iters += 500
+        loss = ag.update(want_loss=True); iters += 0
+        assert loss == loss and abs(loss) < 1e6, f"loss {loss} after {iters} iterations"
+        torch.cuda.synchronize()
+        t = ag.index.buffer(dq._lib.BUF_TREE)
+        bad = (t[k] != t[2 * k] + t[2 * k + 1]).nonzero()
+        assert bad.numel() == 0, (iters, bad[:4].flatten().tolist())
+        assert ag.index.device_errors() == 0
+        assert bool(torch.isfinite(ag.cnn.get_buffer("params")).all())
+        assert ag.cnn.replay_size()[1] == ag.env_steps * 512 and ag.index.replay_size()[1] == (ag.env_steps - 2) * 512
+        checks += 1
+    dt = time.time() - t0
+    print(f"cnn loop (bf16, 512 envs, n-step 3): {iters} iterations in {dt:.1f} s ({iters / dt:.0f}/s incl. checks), loss {loss:.4f}, {checks} checks ok "
+          f"(tree invariant, finite parameters, rings in lockstep, no device error)", flush=True)
+    ag.close()
 
 
 if __name__ == "__main__":
